@@ -1,0 +1,105 @@
+/*
+ * fuzz_vs_ref.c — pins the oracle (zoracle.c) against the unmodified reference
+ * build (oracle/_ref/libzref.so).  TEST INFRASTRUCTURE ONLY.
+ *
+ * For random (data, level, strategy, memLevel, dictionary, flush) tuples it runs
+ * the reference recipe  deflateInit2 / deflateSetDictionary / one deflate() call
+ * and compares the bytes with zo_deflate_chunk().  Also cross-checks checksums
+ * and their combine functions, and inflates every stream with zo_inflate_raw.
+ *
+ * usage: fuzz_vs_ref [iterations] [seed] [max_len]
+ */
+#include "zoracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "zlib.h"   /* the reference's own header, found via -I/root/reference */
+
+static uint64_t rs = 88172645463325252ull;
+static uint32_t rnd(void) { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 32); }
+
+static void gen(uint8_t *b, size_t n)
+{
+    int mode = rnd() % 9;
+    if (mode < 5) { zo_corpus_fill(b, n, mode, rnd() | 1); return; }
+    if (mode == 5) { unsigned a = 1 + rnd() % 16; for (size_t i = 0; i < n; i++) b[i] = (uint8_t)('a' + rnd() % a); return; }
+    if (mode == 6) { unsigned per = 1 + rnd() % 300; for (size_t i = 0; i < n; i++) b[i] = (uint8_t)(i < per ? rnd() : b[i - per]);
+                     for (size_t i = 0; i < n / 97; i++) { b[rnd() % (n ? n : 1)] ^= 1; } return; }
+    if (mode == 7) { memset(b, rnd() & 0xff, n); for (size_t i = 0; i < n / 1000; i++) b[rnd() % (n ? n : 1)] = (uint8_t)rnd(); return; }
+    /* mode 8: copies of earlier material at assorted distances, incl. near MAX_DIST */
+    size_t i = 0;
+    while (i < n) {
+        if (i > 8 && rnd() % 3) {
+            size_t d = (rnd() % 4 == 0) ? 32400 + rnd() % 400 : 1 + rnd() % 40000; if (d > i) d = 1 + rnd() % i;
+            size_t l = 3 + rnd() % 300; for (size_t k = 0; k < l && i < n; k++, i++) b[i] = b[i - d];
+        } else { size_t l = 1 + rnd() % 20; for (size_t k = 0; k < l && i < n; k++, i++) b[i] = (uint8_t)('a' + rnd() % 6); }
+    }
+}
+
+static size_t ref_chunk(const uint8_t *buf, size_t dict, size_t n, int level, int strat, int mem, int final,
+                        uint8_t *out, size_t cap)
+{
+    z_stream z; memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, level, Z_DEFLATED, -15, mem, strat) != Z_OK) return (size_t)-1;
+    if (dict && deflateSetDictionary(&z, buf, (uInt)dict) != Z_OK) { deflateEnd(&z); return (size_t)-1; }
+    z.next_in = (Bytef *)(buf + dict); z.avail_in = (uInt)n; z.next_out = out; z.avail_out = (uInt)cap;
+    int r = deflate(&z, final ? Z_FINISH : Z_SYNC_FLUSH);
+    size_t res = (r == (final ? Z_STREAM_END : Z_OK) && z.avail_in == 0) ? z.total_out : (size_t)-1;
+    deflateEnd(&z);
+    return res;
+}
+
+int main(int argc, char **argv)
+{
+    long iters = argc > 1 ? atol(argv[1]) : 300;
+    if (argc > 2) rs = strtoull(argv[2], 0, 10) | 1;
+    size_t max_len = argc > 3 ? (size_t)atol(argv[3]) : 400000;
+    uint8_t *buf = malloc(32768 + max_len + 16), *o1 = malloc(2 * max_len + 65536), *o2 = malloc(2 * max_len + 65536);
+    uint8_t *back = malloc(max_len + 16);
+    long bad = 0;
+    static const size_t special[] = {0, 1, 2, 3, 4, 261, 262, 263, 16383, 16384, 32506, 32768 - 262 - 3, 32509, 32767, 32768, 32769,
+                                     65274, 65277, 65374, 65535, 65536, 65537, 98000, 131072};
+    for (long it = 0; it < iters; it++) {
+        size_t n;
+        unsigned r = rnd() % 10;
+        if (r < 3) n = special[rnd() % (sizeof special / sizeof *special)];
+        else if (r < 6) n = rnd() % 70000;
+        else n = rnd() % (max_len + 1);
+        if (n > max_len) n = max_len;
+        size_t dict = (rnd() % 3) ? 32768 : (rnd() % 4 ? 0 : rnd() % 32769);
+        int level = 1 + rnd() % 9, strat = rnd() % 5, mem = (rnd() % 3) ? 8 : 1 + rnd() % 9, final = rnd() & 1;
+        if (rnd() % 2) strat = 0;
+        gen(buf, dict + n);
+        size_t cap = 2 * max_len + 65536;
+        size_t a = ref_chunk(buf, dict, n, level, strat, mem, final, o1, cap);
+        zo_trace tr; memset(&tr, 0, sizeof tr);
+        size_t b = zo_deflate_chunk(buf, dict, n, level, strat, mem, 15, final, o2, cap, &tr);
+        int ok = a == b && a != (size_t)-1 && memcmp(o1, o2, a) == 0;
+        /* trace must tile the chunk */
+        if (ok) { uint32_t pos = (uint32_t)dict; for (size_t i = 0; i < tr.n_syms; i++) { if (tr.syms[i].pos != pos) { ok = 0; break; } pos += tr.syms[i].dist ? tr.syms[i].lc + 3u : 1u; } if (pos != dict + n) ok = 0; }
+        if (ok) {   /* inflate with the oracle's decoder */
+            size_t used = 0, made = 0; const char *msg = 0;
+            int rc = zo_inflate_raw(o2, b, buf, dict, back, n, &used, &made, &msg, !final);
+            if (rc != 0 || made != n || used != b || memcmp(back, buf + dict, n)) { ok = 0; fprintf(stderr, "inflate rc=%d made=%zu/%zu used=%zu/%zu msg=%s\n", rc, made, n, used, b, msg ? msg : "-"); }
+        }
+        if (!ok) {
+            bad++;
+            fprintf(stderr, "MISMATCH it=%ld n=%zu dict=%zu L=%d S=%d M=%d final=%d ref=%zu ora=%zu\n", it, n, dict, level, strat, mem, final, a, b);
+            if (bad > 10) break;
+        }
+        zo_trace_free(&tr);
+        /* checksums */
+        uint32_t seedv = rnd();
+        size_t cut = n ? rnd() % (n + 1) : 0;
+        if (adler32(seedv & 0xffffffff, buf, (uInt)n) != zo_adler32(seedv, buf, n) && (seedv & 0xffff) < 65521 && (seedv >> 16) < 65521) { bad++; fprintf(stderr, "adler mismatch\n"); }
+        if (crc32(seedv, buf, (uInt)n) != zo_crc32(seedv, buf, n)) { bad++; fprintf(stderr, "crc mismatch\n"); }
+        uint32_t a1 = zo_adler32(1, buf, cut), a2 = zo_adler32(1, buf + cut, n - cut);
+        uint32_t c1 = zo_crc32(0, buf, cut), c2 = zo_crc32(0, buf + cut, n - cut);
+        if (zo_adler32_combine(a1, a2, (int64_t)(n - cut)) != adler32_combine(a1, a2, (z_off_t)(n - cut)) ||
+            zo_adler32_combine(a1, a2, (int64_t)(n - cut)) != zo_adler32(1, buf, n)) { bad++; fprintf(stderr, "adler combine mismatch\n"); }
+        if (zo_crc32_combine(c1, c2, (int64_t)(n - cut)) != crc32_combine(c1, c2, (z_off_t)(n - cut)) ||
+            zo_crc32_combine(c1, c2, (int64_t)(n - cut)) != zo_crc32(0, buf, n)) { bad++; fprintf(stderr, "crc combine mismatch\n"); }
+    }
+    printf("fuzz_vs_ref: %ld iterations, %ld mismatches\n", iters, bad);
+    return bad != 0;
+}
