@@ -1,0 +1,21 @@
+# Builds the product library (HIP, gfx950) and the test-side oracle.
+HIPCC ?= hipcc
+ARCH ?= gfx950
+SRCS = zlib_amd/csrc/zamd_engine.hip zlib_amd/csrc/zamd_corpus.cpp
+HDRS = zlib_amd/csrc/zamd_core.h include/zamd.h
+
+all: zlib_amd/libzamd.so oracle
+
+zlib_amd/libzamd.so: $(SRCS) $(HDRS)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -o $@ $(SRCS)
+
+oracle:
+	$(MAKE) -C oracle
+
+tests/host_emul: tests/host_emul.cpp zlib_amd/csrc/zamd_core.h oracle/zoracle.c
+	gcc -O2 -c -o /tmp/zoracle_emul.o oracle/zoracle.c
+	g++ -O2 -std=c++17 -I zlib_amd/csrc -I oracle -o $@ tests/host_emul.cpp /tmp/zoracle_emul.o
+
+clean:
+	rm -f zlib_amd/libzamd.so tests/host_emul
+.PHONY: all oracle clean

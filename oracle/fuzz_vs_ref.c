@@ -56,7 +56,7 @@ int main(int argc, char **argv)
     size_t max_len = argc > 3 ? (size_t)atol(argv[3]) : 400000;
     uint8_t *buf = malloc(32768 + max_len + 16), *o1 = malloc(2 * max_len + 65536), *o2 = malloc(2 * max_len + 65536);
     uint8_t *back = malloc(max_len + 16);
-    long bad = 0;
+    long bad = 0, ref_corrupt = 0;
     static const size_t special[] = {0, 1, 2, 3, 4, 261, 262, 263, 16383, 16384, 32506, 32768 - 262 - 3, 32509, 32767, 32768, 32769,
                                      65274, 65277, 65374, 65535, 65536, 65537, 98000, 131072};
     for (long it = 0; it < iters; it++) {
@@ -82,9 +82,23 @@ int main(int argc, char **argv)
             int rc = zo_inflate_raw(o2, b, buf, dict, back, n, &used, &made, &msg, !final);
             if (rc != 0 || made != n || used != b || memcmp(back, buf + dict, n)) { ok = 0; fprintf(stderr, "inflate rc=%d made=%zu/%zu used=%zu/%zu msg=%s\n", rc, made, n, used, b, msg ? msg : "-"); }
         }
+        if (!ok && a != (size_t)-1) {
+            /* zlib 1.2.8 can overrun the pending_buf/d_buf overlay (deflate.h:217-245) when a block
+             * codes to more bytes than the overlay leaves room for (Z_FIXED, tiny memLevel); its output
+             * is then corrupt.  Such cases pin nothing: skip them if the reference cannot inflate itself. */
+            z_stream iz; memset(&iz, 0, sizeof iz); inflateInit2(&iz, -15);
+            if (dict) inflateSetDictionary(&iz, buf, (uInt)dict);
+            iz.next_in = o1; iz.avail_in = (uInt)a; iz.next_out = back; iz.avail_out = (uInt)n;
+            int ir = inflate(&iz, Z_SYNC_FLUSH);
+            int self_ok = (ir == Z_OK || ir == Z_STREAM_END || ir == Z_BUF_ERROR) && iz.total_out == n && memcmp(back, buf + dict, n) == 0;
+            inflateEnd(&iz);
+            if (!self_ok) { ref_corrupt++; ok = 1; fprintf(stderr, "reference output corrupt (does not inflate): it=%ld n=%zu L=%d S=%d M=%d\n", it, n, level, strat, mem); }
+        }
         if (!ok) {
             bad++;
             fprintf(stderr, "MISMATCH it=%ld n=%zu dict=%zu L=%d S=%d M=%d final=%d ref=%zu ora=%zu\n", it, n, dict, level, strat, mem, final, a, b);
+            { size_t d = 0; while (d < a && d < b && o1[d] == o2[d]) d++; fprintf(stderr, "  first diff at byte %zu\n", d);
+              for (size_t i = 0; i < tr.n_blocks && i < 12; i++) fprintf(stderr, "  blk %zu: syms=%u in=[%u,+%u) type=%u can_store=%u opt=%llu static=%llu bits=[%llu,%llu)\n", i, tr.blocks[i].sym_count, tr.blocks[i].in_start, tr.blocks[i].in_len, tr.blocks[i].type, tr.blocks[i].can_store, (unsigned long long)tr.blocks[i].opt_len, (unsigned long long)tr.blocks[i].static_len, (unsigned long long)tr.blocks[i].bit_start, (unsigned long long)tr.blocks[i].bit_end); }
             if (bad > 10) break;
         }
         zo_trace_free(&tr);
@@ -100,6 +114,6 @@ int main(int argc, char **argv)
         if (zo_crc32_combine(c1, c2, (int64_t)(n - cut)) != crc32_combine(c1, c2, (z_off_t)(n - cut)) ||
             zo_crc32_combine(c1, c2, (int64_t)(n - cut)) != zo_crc32(0, buf, n)) { bad++; fprintf(stderr, "crc combine mismatch\n"); }
     }
-    printf("fuzz_vs_ref: %ld iterations, %ld mismatches\n", iters, bad);
+    printf("fuzz_vs_ref: %ld iterations, %ld mismatches, %ld skipped (reference corrupted its own output)\n", iters, bad, ref_corrupt);
     return bad != 0;
 }

@@ -1,0 +1,191 @@
+/*
+ * host_emul.cpp — runs the engine's per-lane building blocks (zamd_core.h) on
+ * the host, chained the way the HIP kernels chain them (chain links -> match
+ * records -> parse -> block plan -> layout -> emit), and compares the bytes
+ * with the CPU oracle.  Test infrastructure: it checks the decomposition, it is
+ * not a CPU code path of the product.
+ *
+ * build: g++ -O2 -I zlib_amd/csrc -I oracle tests/host_emul.cpp oracle/zoracle.c -o tests/host_emul
+ * usage: host_emul [iterations] [seed]
+ */
+#include "zamd_core.h"
+extern "C" {
+#include "zoracle.h"
+}
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+struct HostWin {
+    const uint8_t *b; uint64_t n;    /* b = a-coordinate 0, n = bytes readable */
+    uint32_t load4(uint32_t a) const { uint32_t v = 0; for (int k = 0; k < 4; k++) if ((uint64_t)a + k < n) v |= (uint32_t)b[a + k] << (8 * k); return v; }
+};
+
+static void or_bits(std::vector<uint8_t> &out, uint64_t bit, uint64_t v, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i++, bit++) if ((v >> i) & 1u) out[bit >> 3] |= (uint8_t)(1u << (bit & 7));
+}
+
+static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t chunk_size, int level, int strategy, int mem_level,
+                                         std::vector<uint64_t> &chunk_off)
+{
+    static const uint16_t cfg[10][4] = {{0, 0, 0, 0}, {4, 4, 8, 4}, {4, 5, 16, 8}, {4, 6, 32, 32}, {4, 4, 16, 16},
+                                        {8, 16, 32, 32}, {8, 16, 128, 128}, {8, 32, 128, 256}, {32, 128, 258, 1024}, {32, 258, 258, 4096}};
+    ZcParams P; memset(&P, 0, sizeof P);
+    P.level = level; P.strategy = strategy; P.mem_level = mem_level;
+    P.good = cfg[level][0]; P.lazy = cfg[level][1]; P.nice = cfg[level][2]; P.chain = cfg[level][3];
+    P.hash_bits = mem_level + 7; P.hash_mask = (1u << P.hash_bits) - 1; P.hash_shift = (P.hash_bits + 2) / 3;
+    P.lit_bufsize = 1u << (mem_level + 6);
+    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : ZC_PARSE_SLOW;
+    P.chunk_size = chunk_size; P.max_blocks = chunk_size / (P.lit_bufsize - 1) + 3;
+
+    /* k_chain: global links */
+    std::vector<uint16_t> pdist(n + 4, 0);
+    {
+        std::vector<uint64_t> head((size_t)1 << P.hash_bits, 0);
+        for (uint64_t a = 0; a + 3 <= n; a++) {
+            uint32_t h = zc_hash3(in[a], in[a + 1], in[a + 2], P.hash_shift, P.hash_mask);
+            uint64_t old = head[h]; head[h] = a + 1;
+            uint64_t d = old ? a + 1 - old : 0;
+            pdist[a] = (uint16_t)(d > 32767 ? 0 : d);
+        }
+    }
+    uint64_t chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
+    std::vector<uint8_t> out(n + n / 8 + chunks * 600 + 4096, 0);
+    uint64_t obyte = 0;
+    chunk_off.clear();
+    for (uint64_t c = 0; c < chunks; c++) {
+        ZcChunkGeom g = zc_geom(n, chunk_size, c, 1);
+        uint32_t E = g.dict_len + g.len;
+        HostWin win; win.b = in + g.dstart; win.n = n - g.dstart;
+        const uint16_t *pdc = pdist.data() + g.dstart;
+        auto pd = [&](uint32_t a) { return (uint32_t)pdc[a]; };
+        /* k_match */
+        std::vector<uint32_t> rf(g.len + 1), rq(g.len + 1);
+        if (P.parser == ZC_PARSE_SLOW)
+            for (uint32_t i = 0; i < g.len; i++) zc_match_pos(win, pd, g.dict_len + i, E, g.corner, P.nice, P.chain, &rf[i], &rq[i]);
+        else if (P.parser == ZC_PARSE_RLE)
+            for (uint32_t i = 0; i < g.len; i++) rf[i] = rq[i] = zc_rle_pos(win, g.dict_len + i, E);
+        /* k_parse */
+        std::vector<uint32_t> sym(g.len + 1);
+        std::vector<ZcBlock> blk(P.max_blocks);
+        auto rec = [&](uint32_t p, uint32_t *f, uint32_t *q) { *f = rf[p - g.dict_len]; *q = rq[p - g.dict_len]; };
+        auto symst = [&](uint32_t i, uint32_t w) { sym[i] = w; };
+        auto blkst = [&](uint32_t i, const ZcBlock &b) { if (i >= blk.size()) { fprintf(stderr, "block table overflow\n"); exit(2); } blk[i] = b; };
+        uint32_t nsym = 0, nb;
+        if (P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, P, blkst);
+        else if (P.parser == ZC_PARSE_RLE) nb = zc_parse_rle(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
+        else nb = zc_parse_slow(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
+        /* k_plan */
+        std::vector<ZcBlockTab> tabs(nb);
+        for (uint32_t j = 0; j < nb; j++) {
+            static ZcTree<ZC_L_CODES> lt; static ZcTree<ZC_D_CODES> dt; static ZcTree<ZC_BL_CODES> bt;
+            uint32_t hist[320] = {0};
+            ZcBlock &b = blk[j];
+            for (uint32_t i = 0; i < b.sym_count; i++) {
+                if (b.flags & ZC_BF_IMPLICIT) { hist[win.b[b.in_start + i]]++; continue; }
+                uint32_t s = sym[b.sym_start + i];
+                if (!(s & ZC_SYM_MATCH)) hist[win.b[s]]++;
+                else { hist[257 + zc_len_code((s >> 16) & 0xff)]++; hist[288 + zc_dist_code((s & 0xffff) - 1)]++; }
+            }
+            hist[256] = 1;
+            for (int i = 0; i < ZC_L_CODES; i++) lt.freq[i] = (uint16_t)hist[i];
+            for (int i = 0; i < ZC_D_CODES; i++) dt.freq[i] = (uint16_t)hist[288 + i];
+            uint32_t o1 = 0, s1 = 0, o2 = 0, s2 = 0;
+            zc_build_tree(lt, 15, true, [](int k) { return zc_static_llen((uint32_t)k); },
+                          [](int k) { return k >= 257 ? zc_len_extra((uint32_t)k - 257u) : 0u; }, &o1, &s1);
+            zc_build_tree(dt, 15, true, [](int) { return 5u; }, [](int k) { return zc_dist_extra((uint32_t)k); }, &o2, &s2);
+            zc_plan_block(lt, dt, bt, o1 + o2, s1 + s2, P.strategy, &b, &tabs[j]);
+        }
+        /* k_layout */
+        uint64_t sync = 0;
+        uint64_t cbytes = zc_layout_chunk([&](uint32_t i) { return &blk[i]; }, nb, g.final, &sync);
+        chunk_off.push_back(obyte);
+        uint64_t cbit = obyte * 8;
+        /* k_emit */
+        for (uint32_t j = 0; j < nb; j++) {
+            const ZcBlock &b = blk[j];
+            uint64_t bit = cbit + b.bit_off; uint32_t last = b.flags & ZC_BF_LAST;
+            if (b.type == 0) {
+                or_bits(out, bit, last, 3);
+                uint64_t byte = (bit + 3 + 7) >> 3; uint32_t l = b.in_len & 0xffff;
+                or_bits(out, byte * 8, l | ((~l & 0xffffu) << 16), 32);
+                for (uint32_t i = 0; i < b.in_len; i++) out[byte + 4 + i] |= win.b[b.in_start + i];
+                continue;
+            }
+            or_bits(out, bit, (b.type << 1) | last, 3); bit += 3;
+            for (uint32_t i = 0; i < b.hdr_bits; i++) if ((tabs[j].hdr[i >> 3] >> (i & 7)) & 1) out[(bit + i) >> 3] |= (uint8_t)(1u << ((bit + i) & 7));
+            bit += b.hdr_bits;
+            for (uint32_t i = 0; i <= b.sym_count; i++) {
+                uint64_t v; uint32_t nbits;
+                if (i == b.sym_count) { v = tabs[j].lc[256] & 0xffff; nbits = tabs[j].lc[256] >> 16; }
+                else {
+                    uint32_t s, lit = 0;
+                    if (b.flags & ZC_BF_IMPLICIT) { s = 0; lit = win.b[b.in_start + i]; }
+                    else { s = sym[b.sym_start + i]; if (!(s & ZC_SYM_MATCH)) lit = win.b[s]; }
+                    nbits = zc_sym_bits(s, lit, tabs[j].lc, tabs[j].dc, &v);
+                }
+                or_bits(out, bit, v, nbits); bit += nbits;
+            }
+            if (bit - (cbit + b.bit_off) != b.bits) { fprintf(stderr, "block %u: emitted %llu bits, planned %u\n", j, (unsigned long long)(bit - cbit - b.bit_off), b.bits); exit(3); }
+        }
+        if (!g.final) { uint64_t bit = (cbit + sync + 3 + 7) & ~7ull; or_bits(out, bit + 16, 0xffff, 16); }
+        obyte += cbytes;
+    }
+    chunk_off.push_back(obyte);
+    out.resize(obyte);
+    return out;
+}
+
+static uint64_t rs = 0x9e3779b97f4a7c15ull;
+static uint32_t rnd() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return (uint32_t)(rs >> 32); }
+
+int main(int argc, char **argv)
+{
+    long iters = argc > 1 ? atol(argv[1]) : 60;
+    if (argc > 2) rs = strtoull(argv[2], 0, 10) | 1;
+    /* closed-form code tables vs the reference's tables (via the oracle's trace is indirect; check self-consistency) */
+    for (uint32_t lc = 0; lc < 256; lc++) { uint32_t c = zc_len_code(lc); if (lc < zc_len_base(c) || lc - zc_len_base(c) >= (1u << zc_len_extra(c)) + (c == 28)) { printf("len code table broken at %u\n", lc); return 1; } }
+    for (uint32_t d = 0; d < 32768; d++) { uint32_t c = zc_dist_code(d); if (c >= 30 || d < zc_dist_base(c) || d - zc_dist_base(c) >= (1u << zc_dist_extra(c))) { printf("dist code table broken at %u\n", d); return 1; } }
+    long bad = 0;
+    static const uint32_t chunk_sizes[] = {32768, 49152, 65536, 131072, 262144};
+    static const uint64_t tails[] = {0, 1, 2, 3, 5, 261, 262, 263, 16383, 32506, 32509, 32600, 32767, 65274 - 32768, 65374 - 32768};
+    for (long it = 0; it < iters; it++) {
+        uint32_t cs = chunk_sizes[rnd() % 5];
+        uint64_t n = (uint64_t)(rnd() % 4) * cs + ((rnd() & 1) ? tails[rnd() % 15] % cs : rnd() % cs);
+        if (it == 0) n = 0;
+        if (it == 1) { cs = 65536; n = 65374; }      /* tail-mode slide geometry */
+        int level = 4 + rnd() % 6, strategy = rnd() % 5, mem = (rnd() % 3) ? 8 : 1 + rnd() % 9;
+        if (rnd() & 1) strategy = 0;
+        if (level == 9 && n > 300000) level = 8;
+        std::vector<uint8_t> in(n + 8);
+        int kind = rnd() % 7;
+        if (kind < 5) zo_corpus_fill(in.data(), n, kind, rnd() | 1);
+        else if (kind == 5) for (uint64_t i = 0; i < n; i++) in[i] = (uint8_t)('a' + rnd() % (1 + (it % 16)));
+        else { uint32_t per = 1 + rnd() % 300; for (uint64_t i = 0; i < n; i++) in[i] = (uint8_t)(i < per ? rnd() : in[i - per]); for (uint64_t i = 0; i < n / 211; i++) in[rnd() % n] ^= 4; }
+        std::vector<uint64_t> off;
+        std::vector<uint8_t> got = emul_chunked(in.data(), n, cs, level, strategy, mem, off);
+        std::vector<uint8_t> want(n + n / 4 + 65536);
+        std::vector<uint32_t> clen(n / cs + 2);
+        size_t wl;
+        {   /* oracle chunk loop with the same chunk size */
+            size_t o = 0, offi = 0, c = 0;
+            do {
+                size_t len = n - offi < cs ? n - offi : cs, dict = offi < 32768 ? offi : 32768;
+                size_t r = zo_deflate_chunk(in.data() + offi - dict, dict, len, level, strategy, mem, 15, offi + len >= n, want.data() + o, want.size() - o, NULL);
+                if (r == (size_t)-1) { printf("oracle failed\n"); return 1; }
+                clen[c++] = (uint32_t)r; o += r; offi += len;
+            } while (offi < n);
+            wl = o;
+        }
+        bool ok = got.size() == wl && memcmp(got.data(), want.data(), wl) == 0;
+        if (!ok) {
+            bad++;
+            size_t d = 0; while (d < wl && d < got.size() && got[d] == want[d]) d++;
+            printf("MISMATCH it=%ld n=%llu cs=%u L=%d S=%d M=%d kind=%d got=%zu want=%zu first diff %zu\n", it, (unsigned long long)n, cs, level, strategy, mem, kind, got.size(), wl, d);
+            if (bad > 5) break;
+        }
+    }
+    printf("host_emul: %ld iterations, %ld mismatches\n", iters, bad);
+    return bad != 0;
+}

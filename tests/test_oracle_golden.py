@@ -1,0 +1,172 @@
+"""The CPU oracle against the golden vectors generated from the reference build
+(tests/golden/deflate_golden.json, written by oracle/gen_golden.c) and against the
+behaviours the survey of the reference pinned down.  CPU only."""
+import json
+import os
+import subprocess
+import zlib
+
+import pytest
+
+import _oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "deflate_golden.json")))
+
+
+def _kat_input(name):
+    fib = [1, 1]
+    while len(fib) < 19:
+        fib.append(fib[-1] + fib[-2])
+    return {
+        "a40": b"a" * 40, "empty": b"", "ties64x4": bytes(i for i in range(64) for _ in range(4)),
+        "fib17": bytes(i for i in range(17) for _ in range(fib[i])), "fib19": bytes(i for i in range(19) for _ in range(fib[i])),
+        "range256": bytes(range(256)), "hello": b"hello, hello!\0", "hello_fixed": b"hello, hello!\0",
+        "ab3000c": b"ab" * 3000 + b"c", "a40_rle": b"a" * 40, "ab6z300_rle": b"ab" * 6 + b"z" * 300,
+    }[name]
+
+
+@pytest.mark.parametrize("kat", GOLD["kat"], ids=lambda k: k["name"])
+def test_known_answer_vectors(kat):
+    data = _kat_input(kat["name"])
+    assert len(data) == kat["n"] and "%08x" % zlib.crc32(data) == kat["in_crc"]
+    out = O.deflate_chunk(data, 0, len(data), kat["level"], kat["strategy"], 8, True)
+    assert len(out) == kat["out_len"]
+    assert "%08x" % zlib.crc32(out) == kat["out_crc"]
+    assert out[:256].hex() == kat["out_hex"]
+
+
+# the level-9 rows take the oracle several seconds each; keep the CPU suite to a few minutes
+_ROWS = [r for r in GOLD["chunked"] if not (r["level"] >= 8 and r["n"] > 3_000_000 and r["kind"] != 0)]
+
+
+@pytest.mark.parametrize("row", _ROWS, ids=lambda r: "k%d_s%d_L%d_S%d_M%d_n%d" % (r["kind"], r["seed"], r["level"], r["strategy"], r["mem_level"], r["n"]))
+def test_chunked_rows(row):
+    data = O.corpus(row["n"], row["kind"], row["seed"])
+    assert "%08x" % zlib.adler32(data) == row["in_adler"] and "%08x" % zlib.crc32(data) == row["in_crc"]
+    assert data[:8].hex() == row["head"]
+    out, lens = O.deflate_chunked(data, row["chunk"], row["level"], row["strategy"], row["mem_level"])
+    assert lens == row["chunk_len"]
+    assert len(out) == row["total"] and "%08x" % zlib.crc32(out) == row["out_crc"]
+    off = 0
+    for l, c in zip(lens, row["chunk_crc"]):
+        assert "%08x" % zlib.crc32(out[off:off + l]) == c
+        off += l
+    # the concatenation is one valid raw deflate stream
+    assert zlib.decompress(out, -15) == data
+
+
+def _matches(data, level=6, strategy=0, dict_len=0, final=True):
+    _, syms, blocks = O.deflate_chunk(data, dict_len, len(data) - dict_len, level, strategy, 8, final, want_trace=True)
+    return [(p - dict_len, lc + 3, d) for (p, d, lc) in syms if d], syms, blocks
+
+
+def test_position_zero_is_never_a_match_source():
+    m, syms, blocks = _matches(b"a" * 40)
+    assert m == [(2, 38, 1)] and len(syms) == 3 and blocks[0]["type"] == 1
+    m, _, _ = _matches(b"abc" * 7)
+    assert m == [(4, 17, 3)]
+
+
+def test_block_split_every_lit_bufsize_minus_one_symbols():
+    import random
+    rnd = random.Random(5)
+    data = bytes(rnd.choice(b"abcdefgh") for _ in range(300000))
+    for level in (1, 6):
+        _, _, blocks = _matches(data, level)
+        counts = [b["sym_count"] for b in blocks]
+        assert all(c == 16383 for c in counts[:-1]) and 0 < counts[-1] <= 16383
+        assert all(b["type"] == 2 for b in blocks)
+
+
+def test_too_far_only_in_lazy_parser():
+    import random
+    rnd = random.Random(7)
+    fill = bytes(rnd.choice(b"abcdefghijklmnop") for _ in range(20000))
+    for gap, expect_slow, expect_fast in ((4096, True, True), (4097, False, True)):
+        d = bytearray(fill)
+        d[15000 - gap:15000 - gap + 4] = b"XYZa"
+        d[15000:15004] = b"XYZb"
+        for level in (6, 4, 3, 1):
+            m, _, _ = _matches(bytes(d), level)
+            hit = (15000, 3, gap) in m
+            assert hit == (expect_slow if level >= 4 else expect_fast), (gap, level)
+
+
+def test_tail_mode_slide_loses_the_head_at_max_dist():
+    import random
+    rnd = random.Random(11)
+    for total, expect in ((65374, [(65275, 7, 32506)]), (165374, [(65274, 8, 32506)])):
+        d = bytearray(rnd.choice(b"abcdefghijklmnop") for _ in range(total))
+        d[32768:32776] = b"QRSTUVWX"
+        d[65274:65282] = b"QRSTUVWX"
+        m, _, _ = _matches(bytes(d), 6)
+        got = [x for x in m if 65270 <= x[0] <= 65280]
+        assert got == expect
+
+
+def test_dictionary_matches_from_first_chunk_byte_and_deferred_inserts():
+    import random
+    rnd = random.Random(13)
+    dic = bytearray(rnd.choice(b"abcdefghijklmnop") for _ in range(32768))
+    dic[32000:32010] = b"QRSTUVWXYZ"
+    pay = b"QRSTUVWXYZ" + bytes(rnd.choice(b"abcdefghijklmnop") for _ in range(2000))
+    m, syms, blocks = _matches(bytes(dic) + pay, 6, 0, 32768, final=False)
+    assert m[0] == (0, 10, 768)
+    out = O.deflate_chunk(bytes(dic) + pay, 32768, len(pay), 6, 0, 8, False)
+    assert out[-4:] == b"\x00\x00\xff\xff"
+    dic2 = bytearray(dic); dic2[32766:32768] = b"QR"
+    pay2 = bytearray(rnd.choice(b"abcdefghijklmnop") for _ in range(3000))
+    pay2[0:5] = b"STUVW"; pay2[1000:1007] = b"QRSTUVW"
+    m, _, _ = _matches(bytes(dic2) + bytes(pay2), 6, 0, 32768, final=False)
+    assert (1000, 7, 1002) in m
+
+
+def test_filtered_and_rle_rules():
+    import random
+    rnd = random.Random(17)
+    base = bytearray(rnd.choice(b"abcdefghijklmnop") for _ in range(3000))
+    for ln in (5, 6):
+        d = bytearray(base); s = b"QRSTUV"[:ln]
+        d[500:500 + ln] = s; d[500 + ln] = ord("y"); d[1500:1500 + ln] = s; d[1500 + ln] = ord("z")
+        m_def, _, _ = _matches(bytes(d), 6, 0)
+        m_fil, _, _ = _matches(bytes(d), 6, 1)
+        assert (1500, ln, 1000) in m_def
+        assert ((1500, ln, 1000) in m_fil) == (ln == 6)
+    m, _, _ = _matches(b"a" * 40, 6, 3)
+    assert m == [(1, 39, 1)]
+    m, _, _ = _matches(b"ab" * 6 + b"z" * 300, 6, 3)
+    assert m == [(13, 258, 1), (271, 41, 1)]
+
+
+def test_checksums_and_combine():
+    import random
+    rnd = random.Random(3)
+    data = bytes(rnd.getrandbits(8) for _ in range(100000))
+    assert O.adler32(data) == zlib.adler32(data) and O.crc32(data) == zlib.crc32(data)
+    assert O.adler32(b"") == 1 and O.crc32(b"") == 0
+    for cut in (0, 1, 5552, 65521, 99999, 100000):
+        a1, a2 = zlib.adler32(data[:cut]), zlib.adler32(data[cut:])
+        c1, c2 = zlib.crc32(data[:cut]), zlib.crc32(data[cut:])
+        assert O.lib().zo_adler32_combine(a1, a2, len(data) - cut) == zlib.adler32(data)
+        assert O.lib().zo_crc32_combine(c1, c2, len(data) - cut) == zlib.crc32(data)
+
+
+def test_oracle_inflate_round_trip_and_errors():
+    data = O.corpus(200000, 4, 9)
+    comp = O.deflate_chunk(data, 0, len(data), 6, 0, 8, True)
+    rc, out, used, msg = O.inflate_raw(comp, b"", len(data))
+    assert rc == 0 and out == data and used == len(comp)
+    # error texts of the reference (test/infcover.c:583-613)
+    for hexs, want in (("0e", "invalid block type"), ("0100000000", "invalid stored block lengths"),
+                       ("fc0000", "too many length or distance symbols"), ("04000000fe7f", "invalid code lengths set"),
+                       ("04000000", None)):
+        rc, out, used, msg = O.inflate_raw(bytes.fromhex(hexs), b"", 1000)
+        if want:
+            assert rc == -3 and msg == want, (hexs, rc, msg)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "fuzz_vs_ref")), reason="reference build absent")
+def test_oracle_against_reference_build():
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fuzz_vs_ref"), "150", "2024", "150000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

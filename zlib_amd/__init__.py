@@ -1,0 +1,242 @@
+"""zlib_amd — MI355X-native chunked DEFLATE behind the zlib 1.2.8 API.
+
+Python side of the C ABI in ``include/zamd.h`` (ctypes, no torch types cross the
+boundary).  The compute lives in ``zlib_amd/libzamd.so`` (hand-written HIP for
+gfx950); this module only loads it and mirrors the call shapes of the reference
+(``deflateInit2``/``deflate`` chunk recipe, ``adler32``/``crc32`` with
+``*_combine``).  There is no CPU fallback: if the library or a GPU is missing the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzamd.so")
+
+Z_OK, Z_STREAM_ERROR, Z_DATA_ERROR, Z_MEM_ERROR, Z_BUF_ERROR = 0, -2, -3, -4, -5
+Z_DEFAULT_STRATEGY, Z_FILTERED, Z_HUFFMAN_ONLY, Z_RLE, Z_FIXED = 0, 1, 2, 3, 4
+
+_lib = None
+
+
+class ZamdError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{what} failed with code {code}")
+        self.code = code
+
+
+def load_library() -> C.CDLL:
+    """Loads libzamd.so (built in-tree by ``make`` / ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make zlib_amd/libzamd.so` (hipcc, gfx950)")
+    lib = C.CDLL(LIB_PATH, mode=getattr(os, "RTLD_LOCAL", 0))
+    u64, u32, i32, vp = C.c_uint64, C.c_uint32, C.c_int, C.c_void_p
+    lib.zamd_engine_create.argtypes = [C.POINTER(vp), i32, u64]
+    lib.zamd_engine_create.restype = i32
+    lib.zamd_engine_destroy.argtypes = [vp]
+    lib.zamd_engine_destroy.restype = None
+    lib.zamd_deflate_bound.argtypes = [u64, u32, i32]
+    lib.zamd_deflate_bound.restype = u64
+    lib.zamd_deflate_dev.argtypes = [vp, vp, u64, u32, i32, i32, i32, i32, vp, u64, vp, C.POINTER(u64)]
+    lib.zamd_deflate_dev.restype = i32
+    lib.zamd_checksums_dev.argtypes = [vp, vp, u64, u32, vp, vp]
+    lib.zamd_checksums_dev.restype = i32
+    lib.zamd_adler32_dev.argtypes = [vp, u32, vp, u64, C.POINTER(u32)]
+    lib.zamd_adler32_dev.restype = i32
+    lib.zamd_crc32_dev.argtypes = [vp, u32, vp, u64, C.POINTER(u32)]
+    lib.zamd_crc32_dev.restype = i32
+    lib.zamd_adler32_combine.argtypes = [u32, u32, C.c_int64]
+    lib.zamd_adler32_combine.restype = u32
+    lib.zamd_crc32_combine.argtypes = [u32, u32, C.c_int64]
+    lib.zamd_crc32_combine.restype = u32
+    lib.zamd_inflate_dev.argtypes = [vp, vp, vp, u64, u32, vp, u64, C.POINTER(C.c_int64)]
+    lib.zamd_inflate_dev.restype = i32
+    lib.zamd_last_timing_ms.argtypes = [vp, i32, C.POINTER(i32)]
+    lib.zamd_last_timing_ms.restype = C.c_double
+    lib.zamd_corpus_fill.argtypes = [vp, u64, i32, u64]
+    lib.zamd_corpus_fill.restype = None
+    lib.zamd_corpus_fill_pieces.argtypes = [vp, u64, i32, u64, u64, i32]
+    lib.zamd_corpus_fill_pieces.restype = None
+    lib.zamd_debug_dump.argtypes = [vp, i32, u32, vp, u64]
+    lib.zamd_debug_dump.restype = C.c_int64
+    for name in ("zamd_dev_alloc",):
+        getattr(lib, name).argtypes = [vp, u64, C.POINTER(vp)]
+        getattr(lib, name).restype = i32
+    lib.zamd_dev_free.argtypes = [vp, vp]
+    lib.zamd_dev_free.restype = i32
+    lib.zamd_dev_upload.argtypes = [vp, vp, vp, u64]
+    lib.zamd_dev_upload.restype = i32
+    lib.zamd_dev_download.argtypes = [vp, vp, vp, u64]
+    lib.zamd_dev_download.restype = i32
+    lib.zamd_dev_memset.argtypes = [vp, vp, i32, u64]
+    lib.zamd_dev_memset.restype = i32
+    lib.zamd_version.argtypes = []
+    lib.zamd_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _chk(code: int, what: str) -> None:
+    if code != 0:
+        raise ZamdError(code, what)
+
+
+def corpus(n: int, kind: int, seed: int, piece_bytes: int = 0, threads: int = 1) -> bytearray:
+    """Synthetic corpus (kinds 0 text, 1 binary, 2 lowent, 3 image, 4 mixed)."""
+    lib = load_library()
+    buf = bytearray(n)
+    if n:
+        ptr = (C.c_char * n).from_buffer(buf)
+        if piece_bytes:
+            lib.zamd_corpus_fill_pieces(C.addressof(ptr), n, kind, seed, piece_bytes, threads)
+        else:
+            lib.zamd_corpus_fill(C.addressof(ptr), n, kind, seed)
+    return buf
+
+
+def adler32_combine(a1: int, a2: int, len2: int) -> int:
+    return load_library().zamd_adler32_combine(a1, a2, len2)
+
+
+def crc32_combine(c1: int, c2: int, len2: int) -> int:
+    return load_library().zamd_crc32_combine(c1, c2, len2)
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes on the engine's GPU."""
+
+    def __init__(self, engine: "Engine", nbytes: int):
+        self.engine, self.nbytes = engine, nbytes
+        p = C.c_void_p()
+        _chk(engine.lib.zamd_dev_alloc(engine.handle, nbytes, C.byref(p)), "zamd_dev_alloc")
+        self.ptr = p.value
+
+    def upload(self, data, offset: int = 0) -> None:
+        mv = memoryview(data).cast("B")
+        n = mv.nbytes
+        if n == 0:
+            return
+        if mv.readonly:
+            src = C.c_char_p(bytes(mv))
+            _chk(self.engine.lib.zamd_dev_upload(self.engine.handle, self.ptr + offset, src, n), "zamd_dev_upload")
+        else:
+            arr = (C.c_char * n).from_buffer(mv)
+            _chk(self.engine.lib.zamd_dev_upload(self.engine.handle, self.ptr + offset, C.addressof(arr), n), "zamd_dev_upload")
+
+    def download(self, nbytes: Optional[int] = None, offset: int = 0) -> bytearray:
+        n = self.nbytes - offset if nbytes is None else nbytes
+        out = bytearray(n)
+        if n:
+            arr = (C.c_char * n).from_buffer(out)
+            _chk(self.engine.lib.zamd_dev_download(self.engine.handle, C.addressof(arr), self.ptr + offset, n), "zamd_dev_download")
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            self.engine.lib.zamd_dev_free(self.engine.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One engine per process and GPU (zamd_engine_create)."""
+
+    def __init__(self, device: int = 0, workspace_bytes: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _chk(self.lib.zamd_engine_create(C.byref(h), device, workspace_bytes), "zamd_engine_create")
+        self.handle = h
+        self.device = device
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.zamd_engine_destroy(self.handle)
+            self.handle = None
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    # -- device-resident entry points -------------------------------------------------
+    def deflate_dev(self, d_in: int, n: int, d_out: int, out_cap: int, *, level: int = 6, strategy: int = 0,
+                    mem_level: int = 8, chunk_size: int = 1 << 20, finish: bool = True, d_chunk_off: int = 0) -> int:
+        total = C.c_uint64(0)
+        _chk(self.lib.zamd_deflate_dev(self.handle, d_in, n, chunk_size, level, strategy, mem_level, int(finish),
+                                       d_out, out_cap, d_chunk_off or None, C.byref(total)), "zamd_deflate_dev")
+        return total.value
+
+    def timing_ms(self, which: int) -> Tuple[float, int]:
+        n = C.c_int(0)
+        ms = self.lib.zamd_last_timing_ms(self.handle, which, C.byref(n))
+        return ms, n.value
+
+    def adler32_dev(self, d_in: int, n: int, value: int = 1) -> int:
+        r = C.c_uint32(0)
+        _chk(self.lib.zamd_adler32_dev(self.handle, value, d_in, n, C.byref(r)), "zamd_adler32_dev")
+        return r.value
+
+    def crc32_dev(self, d_in: int, n: int, value: int = 0) -> int:
+        r = C.c_uint32(0)
+        _chk(self.lib.zamd_crc32_dev(self.handle, value, d_in, n, C.byref(r)), "zamd_crc32_dev")
+        return r.value
+
+    # -- host convenience (upload, run on the GPU, download) ---------------------------
+    def deflate_chunks(self, data, *, level: int = 6, strategy: int = 0, mem_level: int = 8,
+                       chunk_size: int = 1 << 20, finish: bool = True) -> Tuple[bytes, List[int]]:
+        """Chunked raw deflate of host bytes; returns (stream, chunk offsets + total)."""
+        n = len(data)
+        nchunks = max(1, (n + chunk_size - 1) // chunk_size)
+        cap = self.lib.zamd_deflate_bound(n, chunk_size, mem_level)
+        d_in = self.alloc(max(n, 16))
+        d_out = self.alloc(cap)
+        d_off = self.alloc(8 * (nchunks + 1))
+        try:
+            d_in.upload(data)
+            total = self.deflate_dev(d_in.ptr, n, d_out.ptr, cap, level=level, strategy=strategy, mem_level=mem_level,
+                                     chunk_size=chunk_size, finish=finish, d_chunk_off=d_off.ptr)
+            out = bytes(d_out.download(total))
+            offs = list(memoryview(d_off.download(8 * (nchunks + 1))).cast("Q"))
+        finally:
+            d_in.free(); d_out.free(); d_off.free()
+        return out, offs
+
+    def adler32(self, data, value: int = 1) -> int:
+        n = len(data)
+        if n == 0:
+            return value
+        d = self.alloc(n)
+        try:
+            d.upload(data)
+            return self.adler32_dev(d.ptr, n, value)
+        finally:
+            d.free()
+
+    def crc32(self, data, value: int = 0) -> int:
+        n = len(data)
+        if n == 0:
+            return value
+        d = self.alloc(n)
+        try:
+            d.upload(data)
+            return self.crc32_dev(d.ptr, n, value)
+        finally:
+            d.free()
+
+    def debug_dump(self, what: int, chunk: int, max_elems: int, elem_bytes: int) -> bytearray:
+        buf = bytearray(max_elems * elem_bytes)
+        arr = (C.c_char * len(buf)).from_buffer(buf)
+        cnt = self.lib.zamd_debug_dump(self.handle, what, chunk, C.addressof(arr), max_elems)
+        if cnt < 0:
+            raise ZamdError(int(cnt), "zamd_debug_dump")
+        del arr
+        return buf[: cnt * elem_bytes]

@@ -1,0 +1,635 @@
+/*
+ * zamd_core.h — shared per-lane building blocks of the MI355X DEFLATE engine.
+ *
+ * Everything here is `__host__ __device__`: the HIP kernels in zamd_kernels.hip
+ * call these functions from device code, and tests/host_emul.cpp runs the same
+ * functions on the host to check the pipeline's decomposition without a GPU.
+ *
+ * Coordinates: a chunk is addressed in "a-coordinates": a = 0 is the first byte
+ * of the chunk's dictionary (the 32 KiB of input before the chunk, or the chunk
+ * itself when it is the first one), the chunk's own bytes are
+ * [dict_len, dict_len + len).  Window index 0 of the reference (deflate.c:104,
+ * NIL) is therefore a = 0 until the first window slide.
+ *
+ * Citations are file:line in zlib 1.2.8.
+ */
+#ifndef ZAMD_CORE_H
+#define ZAMD_CORE_H
+
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZC_HD __host__ __device__ inline
+#else
+#define ZC_HD inline
+#endif
+
+#define ZC_WSIZE     32768u                 /* windowBits 15 */
+#define ZC_MIN_MATCH 3u                     /* zutil.h:75 */
+#define ZC_MAX_MATCH 258u                   /* zutil.h:76 */
+#define ZC_MIN_LOOK  262u                   /* deflate.h:281 */
+#define ZC_MAX_DIST  (ZC_WSIZE - ZC_MIN_LOOK)   /* deflate.h:286 */
+#define ZC_TOO_FAR   4096u                  /* deflate.c:107 */
+#define ZC_L_CODES   286
+#define ZC_D_CODES   30
+#define ZC_BL_CODES  19
+#define ZC_END_BLOCK 256
+#define ZC_NO_CORNER 0xffffffffu
+
+enum { ZC_PARSE_SLOW = 0, ZC_PARSE_FAST = 1, ZC_PARSE_RLE = 2, ZC_PARSE_HUFF = 3 };
+enum { ZC_STRAT_DEFAULT = 0, ZC_STRAT_FILTERED = 1, ZC_STRAT_HUFF = 2, ZC_STRAT_RLE = 3, ZC_STRAT_FIXED = 4 };
+
+/* block flags */
+#define ZC_BF_LAST      1u    /* BFINAL */
+#define ZC_BF_CANSTORE  2u    /* block start still inside the window (deflate.c:1539) */
+#define ZC_BF_IMPLICIT  4u    /* symbols are the literal bytes of the block, no symbol buffer */
+
+struct ZcParams {
+    uint32_t level, strategy, mem_level;
+    uint32_t good, lazy, nice, chain;          /* configuration_table, deflate.c:131-143 */
+    uint32_t hash_bits, hash_shift, hash_mask; /* deflate.c:284-291 */
+    uint32_t lit_bufsize;                      /* deflate.c:299 */
+    uint32_t parser;                           /* ZC_PARSE_* */
+    uint32_t chunk_size;
+    uint32_t max_blocks;                       /* per-chunk capacity of the block table */
+};
+
+struct ZcBlock {                 /* one _tr_flush_block() call */
+    uint32_t sym_start, sym_count;
+    uint32_t in_start, in_len;   /* a-coordinates / stored_len */
+    uint32_t flags;
+    uint32_t type;               /* 0 stored, 1 static, 2 dynamic (set by the planner) */
+    uint32_t bits;               /* non-stored: 3 + coded bits; stored: unused */
+    uint32_t hdr_bits;           /* dynamic: bits of the tree header after the 3 type bits */
+    uint64_t bit_off;            /* absolute bit offset in the output buffer */
+};
+
+struct ZcChunkGeom {
+    uint64_t dstart;             /* absolute offset of a = 0 */
+    uint32_t dict_len, len, final, corner;
+};
+
+/* Chunk c of an n-byte input cut every chunk_size bytes.  `corner` is the one
+ * position whose head candidate at distance exactly MAX_DIST is lost to a
+ * window slide in tail mode (fill_window called with no input left,
+ * deflate.c:1419-1451), or ZC_NO_CORNER. */
+ZC_HD ZcChunkGeom zc_geom(uint64_t n, uint32_t chunk_size, uint64_t c, int finish)
+{
+    ZcChunkGeom g;
+    uint64_t start = c * (uint64_t)chunk_size;
+    uint64_t rem = n - start;
+    g.len = (uint32_t)(rem < chunk_size ? rem : chunk_size);
+    g.dict_len = (uint32_t)(start < ZC_WSIZE ? start : ZC_WSIZE);
+    g.dstart = start - g.dict_len;
+    g.final = (finish && start + g.len >= n) ? 1u : 0u;
+    uint32_t E = g.dict_len + g.len;
+    uint32_t bt = E <= 2 * ZC_WSIZE ? 0u : ((E - 2 * ZC_WSIZE + ZC_WSIZE - 1) / ZC_WSIZE) * ZC_WSIZE;
+    uint32_t tail = E - bt;       /* data end as a window index in the last window */
+    g.corner = (tail >= ZC_WSIZE + ZC_MAX_DIST + 3 && tail <= 2 * ZC_WSIZE - 1) ? bt + ZC_WSIZE + ZC_MAX_DIST : ZC_NO_CORNER;
+    return g;
+}
+
+ZC_HD uint32_t zc_hash3(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t shift, uint32_t mask)
+{   /* three UPDATE_HASH steps, deflate.c:167 */
+    return ((((b0 << shift) ^ b1) << shift) ^ b2) & mask;
+}
+
+ZC_HD uint32_t zc_ctz32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__ffs((int)x) - 1u;
+#else
+    return (uint32_t)__builtin_ctz(x);
+#endif
+}
+ZC_HD uint32_t zc_clz32(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__clz((int)x);
+#else
+    return (uint32_t)__builtin_clz(x);
+#endif
+}
+ZC_HD uint32_t zc_bitrev(uint32_t v, uint32_t n)        /* bi_reverse, trees.c:1154 */
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32u - n);
+#else
+    uint32_t r = 0;
+    for (uint32_t i = 0; i < n; i++) { r = (r << 1) | (v & 1u); v >>= 1; }
+    return r;
+#endif
+}
+
+/* ------------------------------------------------------------------ symbol codes
+ * Closed forms of _length_code / _dist_code / base_length / base_dist /
+ * extra_lbits / extra_dbits (trees.c:62-66, 257-288). */
+ZC_HD uint32_t zc_len_code(uint32_t lc)           /* lc = length - 3, 0..255 */
+{
+    if (lc < 8) return lc;
+    if (lc == 255) return 28;
+    uint32_t e = 29u - zc_clz32(lc);              /* floor(log2 lc) - 2 */
+    return 4u * e + 4u + ((lc >> e) & 3u);
+}
+ZC_HD uint32_t zc_len_extra(uint32_t code) { return (code < 8 || code == 28) ? 0u : (code >> 2) - 1u; }
+ZC_HD uint32_t zc_len_base(uint32_t code)
+{
+    if (code < 8) return code;
+    if (code == 28) return 255;
+    return (4u + (code & 3u)) << ((code >> 2) - 1u);
+}
+ZC_HD uint32_t zc_dist_code(uint32_t d)           /* d = distance - 1, 0..32767 */
+{
+    if (d < 4) return d;
+    uint32_t hb = 31u - zc_clz32(d);
+    return 2u * hb + ((d >> (hb - 1u)) & 1u);
+}
+ZC_HD uint32_t zc_dist_extra(uint32_t code) { return code < 4 ? 0u : (code >> 1) - 1u; }
+ZC_HD uint32_t zc_dist_base(uint32_t code) { return code < 4 ? code : (2u + (code & 1u)) << ((code >> 1) - 1u); }
+
+/* static literal/length tree (trees.c:291-301): returns code | len<<16 */
+ZC_HD uint32_t zc_static_lcode(uint32_t n)
+{
+    uint32_t len, c;
+    if (n <= 143) { len = 8; c = 0x30 + n; }
+    else if (n <= 255) { len = 9; c = 0x190 + (n - 144); }
+    else if (n <= 279) { len = 7; c = n - 256; }
+    else { len = 8; c = 0xC0 + (n - 280); }
+    return zc_bitrev(c, len) | (len << 16);
+}
+ZC_HD uint32_t zc_static_llen(uint32_t n) { return n <= 143 ? 8u : n <= 255 ? 9u : n <= 279 ? 7u : 8u; }
+ZC_HD uint32_t zc_static_dcode(uint32_t n) { return zc_bitrev(n, 5) | (5u << 16); }
+
+/* Symbol word written by the parsers: literal = a-coordinate of the byte
+ * (bit 31 clear); match = bit 31 | (length-3) << 16 | distance. */
+#define ZC_SYM_MATCH 0x80000000u
+ZC_HD uint32_t zc_sym_match(uint32_t len, uint32_t dist) { return ZC_SYM_MATCH | ((len - 3u) << 16) | dist; }
+
+/* compress_block() for one symbol (trees.c:1072-1096): bits LSB-first in *v.
+ * ltab/dtab hold code | len<<16 per symbol. */
+template <class LTab, class DTab>
+ZC_HD uint32_t zc_sym_bits(uint32_t sym, uint32_t lit_byte, const LTab &ltab, const DTab &dtab, uint64_t *v)
+{
+    if (!(sym & ZC_SYM_MATCH)) {
+        uint32_t e = ltab[lit_byte];
+        *v = e & 0xffffu;
+        return e >> 16;
+    }
+    uint32_t lc = (sym >> 16) & 0xffu, d = (sym & 0xffffu) - 1u;
+    uint32_t c = zc_len_code(lc), e = ltab[c + 257u];
+    uint64_t acc = e & 0xffffu; uint32_t n = e >> 16;
+    uint32_t xb = zc_len_extra(c);
+    acc |= (uint64_t)(lc - zc_len_base(c)) << n; n += xb;
+    c = zc_dist_code(d); e = dtab[c];
+    acc |= (uint64_t)(e & 0xffffu) << n; n += e >> 16;
+    xb = zc_dist_extra(c);
+    acc |= (uint64_t)(d - zc_dist_base(c)) << n; n += xb;
+    *v = acc;
+    return n;
+}
+
+/* ------------------------------------------------------------------ match search
+ * longest_match() (deflate.c:1148-1289) evaluated without knowing the parser's
+ * state.  For levels 4-9 every string with three bytes of lookahead is inserted
+ * in order (deflate.c:1757, 1806-1810), so the chain of p is "all earlier
+ * positions with p's hash, newest first" and can be walked ahead of the parse.
+ * The walk starts from best_len = 2 and keeps the last strictly-longer
+ * candidate seen within each of the two chain budgets the parser can ask for
+ * (max_chain, or max_chain >> 2 when prev_length >= good_match, :1185-1187),
+ * stopping at the first candidate of nice length (:1276).  The parser then
+ * accepts the recorded match iff it is longer than its prev_length, which is
+ * what starting the walk from best_len = prev_length does.
+ *
+ * Win::load4(a) returns the 4 input bytes at a-coordinate a (little endian),
+ * pd(a) the distance from a to the previous string with the same hash (0 =
+ * none within 32767).  Result words: len | dist << 16, len = 0 for "no match".
+ */
+template <class Win, class Pd>
+ZC_HD void zc_match_pos(const Win &win, const Pd &pd, uint32_t p, uint32_t E, uint32_t corner,
+                        uint32_t nice_match, uint32_t max_chain, uint32_t *rec_full, uint32_t *rec_quarter)
+{
+    *rec_full = 0; *rec_quarter = 0;
+    uint32_t look = E - p;
+    if (look < ZC_MIN_MATCH) return;                       /* no INSERT_STRING, deflate.c:1756 */
+    uint32_t d0 = pd(p);
+    if (d0 == 0 || d0 > ZC_MAX_DIST) return;               /* hash_head == NIL or too far, :1765-1766 */
+    uint32_t cur = p - d0;
+    if (cur == 0) return;                                  /* window index 0 is NIL */
+    if (p == corner && d0 == ZC_MAX_DIST) return;          /* slid onto index 0 in tail mode */
+    uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
+    uint32_t nice = nice_match < look ? nice_match : look; /* :1191 */
+    uint32_t qbudget = max_chain >> 2;
+    uint32_t best = ZC_MIN_MATCH - 1, bdist = 0, k = 0, qrec = 0;
+    bool qset = false;
+    for (;;) {
+        /* candidate `cur` can only beat `best` if bytes best-2..best agree (and best < cap) */
+        uint32_t off = best - 2u;                          /* >= 0 */
+        uint32_t mask = 0x00ffffffu;
+        if (((win.load4(cur + off) ^ win.load4(p + off)) & mask) == 0) {
+            uint32_t len = 0;
+            while (len < cap) {
+                uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
+                if (x) { len += zc_ctz32(x) >> 3; break; }
+                len += 4;
+            }
+            if (len > cap) len = cap;
+            if (len > best) {
+                best = len; bdist = p - cur;
+                if (len >= nice) { k++; break; }
+            }
+        }
+        k++;
+        if (k == qbudget) { qrec = best >= ZC_MIN_MATCH ? (best | (bdist << 16)) : 0; qset = true; }
+        if (k >= max_chain) break;
+        uint32_t d = pd(cur);
+        if (d == 0) break;
+        if (d >= cur) break;                               /* would reach a <= 0: NIL */
+        cur -= d;
+        if (p - cur >= ZC_MAX_DIST) break;                 /* cur <= limit, :1158, 1284 */
+    }
+    uint32_t full = best >= ZC_MIN_MATCH ? (best | (bdist << 16)) : 0;
+    *rec_full = full;
+    *rec_quarter = (qset && k > qbudget) ? qrec : full;
+    if (qbudget == 0) *rec_quarter = 0;
+}
+
+/* Z_RLE (deflate.c:1884-1898): run of bytes equal to the previous byte. */
+template <class Win>
+ZC_HD uint32_t zc_rle_pos(const Win &win, uint32_t p, uint32_t E)
+{
+    uint32_t look = E - p;
+    if (look < ZC_MIN_MATCH || p == 0) return 0;
+    uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
+    uint32_t c = win.load4(p - 1) & 0xffu, pat = c * 0x01010101u, len = 0;
+    while (len < cap) {
+        uint32_t x = win.load4(p + len) ^ pat;
+        if (x) { len += zc_ctz32(x) >> 3; break; }
+        len += 4;
+    }
+    if (len > cap) len = cap;
+    return len >= ZC_MIN_MATCH ? (len | (1u << 16)) : 0;
+}
+
+/* ------------------------------------------------------------------ parsers
+ * Window bookkeeping shared by all parsers: fill_window() for a call that hands
+ * over the whole chunk (deflate.c:1390-1494).  B = a-coordinate of window index
+ * 0, wend = end of the data currently in the window. */
+struct ZcWindow {
+    uint32_t B, wend, E;
+    ZC_HD void refill(uint32_t p)
+    {
+        if (p - B >= ZC_WSIZE + ZC_MAX_DIST) B += ZC_WSIZE;
+        uint64_t cap = (uint64_t)B + 2u * ZC_WSIZE;
+        wend = E < cap ? E : (uint32_t)cap;
+    }
+};
+
+/* Common symbol/block sink.  Sym(i, word) stores symbol i, Blk(i, ZcBlock) block i. */
+template <class Sym, class Blk>
+struct ZcSink {
+    Sym sym; Blk blk;
+    uint32_t nsym, blk_sym0, bstart, nblk, lim;
+    ZC_HD ZcSink(Sym s, Blk b, uint32_t start, uint32_t lit_bufsize)
+        : sym(s), blk(b), nsym(0), blk_sym0(0), bstart(start), nblk(0), lim(lit_bufsize - 1) {}
+    ZC_HD bool emit(uint32_t word)                 /* _tr_tally, trees.c:1010-1050 */
+    {
+        sym(nsym++, word);
+        return nsym - blk_sym0 == lim;
+    }
+    ZC_HD void flush(uint32_t p, uint32_t last, const ZcWindow &w, uint32_t extra_flags = 0)
+    {   /* FLUSH_BLOCK_ONLY, deflate.c:1538-1547 */
+        ZcBlock b;
+        b.sym_start = blk_sym0; b.sym_count = nsym - blk_sym0;
+        b.in_start = bstart; b.in_len = p - bstart;
+        b.flags = (last ? ZC_BF_LAST : 0u) | (bstart >= w.B ? ZC_BF_CANSTORE : 0u) | extra_flags;
+        b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
+        blk(nblk++, b);
+        blk_sym0 = nsym; bstart = p;
+    }
+};
+
+/* deflate_slow() (deflate.c:1730-1853) replayed over the precomputed match
+ * records.  Rec(p, &full, &quarter) loads the record of a-coordinate p.
+ * Returns the number of blocks; *nsym_out receives the symbol count. */
+template <class Rec, class Sym, class Blk>
+ZC_HD uint32_t zc_parse_slow(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P,
+                             Rec rec, Sym sym, Blk blk, uint32_t *nsym_out)
+{
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    ZcSink<Sym, Blk> out(sym, blk, dict_len, P.lit_bufsize);
+    uint32_t p = dict_len, mlen = ZC_MIN_MATCH - 1, mdist = 0, avail = 0;
+    for (;;) {
+        if (w.wend - p < ZC_MIN_LOOK) { w.refill(p); if (w.wend == p) break; }
+        uint32_t plen = mlen, pdist = mdist;
+        mlen = ZC_MIN_MATCH - 1;
+        if (plen < P.lazy && w.wend - p >= ZC_MIN_MATCH) {
+            uint32_t rf, rq; rec(p, &rf, &rq);
+            uint32_t v = plen >= P.good ? rq : rf;
+            uint32_t l = v & 0xffffu, d = v >> 16;
+            if (l > plen &&
+                !(l <= 5 && (P.strategy == ZC_STRAT_FILTERED || (l == ZC_MIN_MATCH && d > ZC_TOO_FAR)))) {
+                mlen = l; mdist = d;                       /* :1771-1785 */
+            }
+        }
+        if (plen >= ZC_MIN_MATCH && mlen <= plen) {        /* :1790-1815 */
+            bool f = out.emit(zc_sym_match(plen, pdist));
+            p += plen - 1; avail = 0; mlen = ZC_MIN_MATCH - 1;
+            if (f) out.flush(p, 0, w);
+        } else if (avail) {                                /* :1817-1829 */
+            if (out.emit(p - 1)) out.flush(p, 0, w);
+            p++;
+        } else { avail = 1; p++; }                         /* :1830-1837 */
+    }
+    if (avail) out.emit(p - 1);                            /* :1840-1844 */
+    if (final_) out.flush(p, 1, w);
+    else if (out.nsym != out.blk_sym0) out.flush(p, 0, w);
+    *nsym_out = out.nsym;
+    return out.nblk;
+}
+
+/* deflate_rle() (deflate.c:1861-1928) over precomputed run lengths. */
+template <class Rec, class Sym, class Blk>
+ZC_HD uint32_t zc_parse_rle(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P,
+                            Rec rec, Sym sym, Blk blk, uint32_t *nsym_out)
+{
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    ZcSink<Sym, Blk> out(sym, blk, dict_len, P.lit_bufsize);
+    uint32_t p = dict_len;
+    for (;;) {
+        if (w.wend - p <= ZC_MAX_MATCH) { w.refill(p); if (w.wend == p) break; }
+        uint32_t l = 0;
+        if (w.wend - p >= ZC_MIN_MATCH && p > w.B) { uint32_t rf, rq; rec(p, &rf, &rq); l = rf & 0xffffu; }
+        bool f;
+        if (l >= ZC_MIN_MATCH) { f = out.emit(zc_sym_match(l, 1)); p += l; }
+        else { f = out.emit(p); p++; }
+        if (f) out.flush(p, 0, w);
+    }
+    if (final_) out.flush(p, 1, w);
+    else if (out.nsym != out.blk_sym0) out.flush(p, 0, w);
+    *nsym_out = out.nsym;
+    return out.nblk;
+}
+
+/* deflate_huff() (deflate.c:1934-1967): every byte a literal, so the block
+ * table follows from the chunk length alone. */
+template <class Blk>
+ZC_HD uint32_t zc_parse_huff(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P, Blk blk)
+{
+    uint32_t lim = P.lit_bufsize - 1, nblk = 0, done = 0;
+    while (len - done >= lim) {
+        ZcBlock b; b.sym_start = done; b.sym_count = lim; b.in_start = dict_len + done; b.in_len = lim;
+        b.flags = ZC_BF_CANSTORE | ZC_BF_IMPLICIT; b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
+        blk(nblk++, b); done += lim;
+    }
+    if (final_ || len != done) {
+        ZcBlock b; b.sym_start = done; b.sym_count = len - done; b.in_start = dict_len + done; b.in_len = len - done;
+        b.flags = ZC_BF_CANSTORE | ZC_BF_IMPLICIT | (final_ ? ZC_BF_LAST : 0u); b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
+        blk(nblk++, b);
+    }
+    return nblk;
+}
+
+/* ------------------------------------------------------------------ Huffman
+ * build_tree / gen_bitlen (trees.c:488-565, 617-699) executed by one lane.
+ * N = number of leaves, HEAP = 2N+1.  freq[] holds leaf frequencies on entry
+ * (internal nodes are written during construction); len[] receives the code
+ * lengths, bl_count[] the per-length counts for gen_codes. */
+template <int N>
+struct ZcTree {
+    enum { HEAP = 2 * N + 1 };
+    uint16_t freq[HEAP];
+    uint16_t dad[HEAP];
+    uint16_t heap[HEAP];
+    uint8_t  len[HEAP + 3];
+    uint8_t  depth[HEAP + 3];
+    uint16_t bl_count[16];
+    int32_t  max_code;
+};
+
+template <int N>
+ZC_HD bool zc_smaller(const ZcTree<N> &t, uint32_t n, uint32_t m)   /* trees.c:443 */
+{
+    uint32_t fn = t.freq[n], fm = t.freq[m];
+    return fn < fm || (fn == fm && t.depth[n] <= t.depth[m]);
+}
+template <int N>
+ZC_HD void zc_sift(ZcTree<N> &t, int heap_len, int k)               /* pqdownheap, trees.c:453 */
+{
+    uint32_t v = t.heap[k];
+    int j = k << 1;
+    while (j <= heap_len) {
+        if (j < heap_len && zc_smaller(t, t.heap[j + 1], t.heap[j])) j++;
+        if (zc_smaller(t, v, t.heap[j])) break;
+        t.heap[k] = t.heap[j]; k = j; j <<= 1;
+    }
+    t.heap[k] = (uint16_t)v;
+}
+
+/* stlen(n) = static code length of symbol n (or 0 when the tree has no static
+ * counterpart), xbits(n) = extra bits of symbol n. */
+template <int N, class StLen, class XBits>
+ZC_HD void zc_build_tree(ZcTree<N> &t, int max_length, bool has_static, StLen stlen, XBits xbits,
+                         uint32_t *opt_len, uint32_t *static_len)
+{
+    const int HEAP = ZcTree<N>::HEAP;
+    int heap_len = 0, heap_max = HEAP, max_code = -1, n, m, node;
+    for (n = 0; n < N; n++) {
+        if (t.freq[n] != 0) { t.heap[++heap_len] = (uint16_t)(max_code = n); t.depth[n] = 0; }
+        else t.len[n] = 0;
+    }
+    while (heap_len < 2) {                                           /* trees.c:648-654 */
+        node = (max_code < 2 ? ++max_code : 0);
+        t.heap[++heap_len] = (uint16_t)node;
+        t.freq[node] = 1; t.depth[node] = 0;
+        (*opt_len)--; if (has_static) *static_len -= stlen(node);
+    }
+    t.max_code = max_code;
+    for (n = heap_len / 2; n >= 1; n--) zc_sift(t, heap_len, n);
+    node = N;
+    do {
+        n = t.heap[1]; t.heap[1] = t.heap[heap_len--]; zc_sift(t, heap_len, 1);
+        m = t.heap[1];
+        t.heap[--heap_max] = (uint16_t)n; t.heap[--heap_max] = (uint16_t)m;
+        t.freq[node] = (uint16_t)(t.freq[n] + t.freq[m]);
+        uint32_t dn = t.depth[n], dm = t.depth[m];
+        t.depth[node] = (uint8_t)((dn >= dm ? dn : dm) + 1);
+        t.dad[n] = t.dad[m] = (uint16_t)node;
+        t.heap[1] = (uint16_t)node++;
+        zc_sift(t, heap_len, 1);
+    } while (heap_len >= 2);
+    t.heap[--heap_max] = t.heap[1];
+
+    /* gen_bitlen */
+    int h, bits, overflow = 0;
+    for (bits = 0; bits <= 15; bits++) t.bl_count[bits] = 0;
+    t.len[t.heap[heap_max]] = 0;
+    for (h = heap_max + 1; h < HEAP; h++) {
+        n = t.heap[h];
+        bits = t.len[t.dad[n]] + 1;
+        if (bits > max_length) { bits = max_length; overflow++; }
+        t.len[n] = (uint8_t)bits;
+        if (n > max_code) continue;
+        t.bl_count[bits]++;
+        uint32_t xb = xbits(n), f = t.freq[n];
+        *opt_len += f * ((uint32_t)bits + xb);
+        if (has_static) *static_len += f * (stlen(n) + xb);
+    }
+    if (overflow == 0) return;
+    do {
+        bits = max_length - 1;
+        while (t.bl_count[bits] == 0) bits--;
+        t.bl_count[bits]--; t.bl_count[bits + 1] += 2; t.bl_count[max_length]--;
+        overflow -= 2;
+    } while (overflow > 0);
+    for (bits = max_length; bits != 0; bits--) {
+        n = t.bl_count[bits];
+        while (n != 0) {
+            m = t.heap[--h];
+            if (m > max_code) continue;
+            if ((int)t.len[m] != bits) {
+                *opt_len += (uint32_t)((bits - (int)t.len[m]) * (int)t.freq[m]);
+                t.len[m] = (uint8_t)bits;
+            }
+            n--;
+        }
+    }
+}
+
+/* gen_codes (trees.c:575-607): code | len<<16 for symbols 0..max_code into tab[]. */
+template <int N, class Tab>
+ZC_HD void zc_assign_codes(const ZcTree<N> &t, Tab &tab, int count)
+{
+    uint32_t next[16], c = 0;
+    for (int b = 1; b <= 15; b++) { c = (c + t.bl_count[b - 1]) << 1; next[b] = c; }
+    for (int n = 0; n < count; n++) {
+        uint32_t l = n <= t.max_code ? t.len[n] : 0u;
+        tab[n] = l ? (zc_bitrev(next[l]++, l) | (l << 16)) : 0u;
+    }
+}
+
+/* LSB-first bit writer into a byte array that starts zeroed (send_bits, trees.c:213). */
+struct ZcBitW {
+    uint8_t *buf; uint32_t nbits;
+    ZC_HD void put(uint32_t v, uint32_t n)
+    {
+        uint32_t pos = nbits; nbits += n;
+        while (n) {
+            uint32_t sh = pos & 7u, room = 8u - sh, take = n < room ? n : room;
+            buf[pos >> 3] = (uint8_t)(buf[pos >> 3] | ((v & ((1u << take) - 1u)) << sh));
+            v >>= take; n -= take; pos += take;
+        }
+    }
+};
+
+/* scan_tree / send_tree (trees.c:705-795).  With w == nullptr counts the
+ * bit-length symbols into blfreq[], else writes them with the codes in bltab. */
+template <class Len>
+ZC_HD void zc_walk_lengths(Len len, int max_code, uint16_t *blfreq, const uint32_t *bltab, ZcBitW *w)
+{
+    int prevlen = -1, curlen, nextlen = (int)len(0), count = 0, maxc = 7, minc = 4;
+    if (nextlen == 0) { maxc = 138; minc = 3; }
+    for (int n = 0; n <= max_code; n++) {
+        curlen = nextlen; nextlen = (n == max_code) ? 0xffff : (int)len(n + 1);
+        if (++count < maxc && curlen == nextlen) continue;
+        if (count < minc) {
+            if (w) { do w->put(bltab[curlen] & 0xffffu, bltab[curlen] >> 16); while (--count); }
+            else blfreq[curlen] = (uint16_t)(blfreq[curlen] + count);
+        } else if (curlen != 0) {
+            if (curlen != prevlen) {
+                if (w) { w->put(bltab[curlen] & 0xffffu, bltab[curlen] >> 16); count--; }
+                else blfreq[curlen]++;
+            }
+            if (w) { w->put(bltab[16] & 0xffffu, bltab[16] >> 16); w->put((uint32_t)(count - 3), 2); }
+            else blfreq[16]++;
+        } else if (count <= 10) {
+            if (w) { w->put(bltab[17] & 0xffffu, bltab[17] >> 16); w->put((uint32_t)(count - 3), 3); }
+            else blfreq[17]++;
+        } else {
+            if (w) { w->put(bltab[18] & 0xffffu, bltab[18] >> 16); w->put((uint32_t)(count - 11), 7); }
+            else blfreq[18]++;
+        }
+        count = 0; prevlen = curlen;
+        if (nextlen == 0) { maxc = 138; minc = 3; }
+        else if (curlen == nextlen) { maxc = 6; minc = 3; }
+        else { maxc = 7; minc = 4; }
+    }
+}
+
+#define ZC_HDR_BYTES 320     /* 14 + 19*3 + 316*7 bits = 2283 bits < 2560 */
+
+/* Per-block coding tables produced by the planner and read by the emitter. */
+struct ZcBlockTab {
+    uint32_t lc[288];        /* code | len<<16 */
+    uint32_t dc[32];
+    uint8_t  hdr[ZC_HDR_BYTES];
+};
+
+/* The serial tail of _tr_flush_block() (trees.c:938-989) once the literal and
+ * distance trees exist: bit-length tree, cost comparison, block type, header
+ * bits and code tables.  Runs on one lane. */
+ZC_HD void zc_plan_block(ZcTree<ZC_L_CODES> &lt, ZcTree<ZC_D_CODES> &dt, ZcTree<ZC_BL_CODES> &bt,
+                         uint32_t opt_len, uint32_t static_len, uint32_t strategy,
+                         ZcBlock *b, ZcBlockTab *tab)
+{
+    static const uint8_t bl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (int i = 0; i < ZC_BL_CODES; i++) bt.freq[i] = 0;
+    /* build_bl_tree, trees.c:801-829 */
+    zc_walk_lengths([&](int n) { return lt.len[n]; }, lt.max_code, bt.freq, nullptr, nullptr);
+    zc_walk_lengths([&](int n) { return dt.len[n]; }, dt.max_code, bt.freq, nullptr, nullptr);
+    uint32_t dummy = 0;
+    zc_build_tree(bt, 7, false, [](int) { return 0u; },
+                  [](int n) { return n == 16 ? 2u : n == 17 ? 3u : n == 18 ? 7u : 0u; }, &opt_len, &dummy);
+    int max_bl;
+    for (max_bl = ZC_BL_CODES - 1; max_bl >= 3; max_bl--) if (bt.len[bl_order[max_bl]] != 0) break;
+    opt_len += 3u * ((uint32_t)max_bl + 1u) + 5u + 5u + 4u;
+    uint32_t opt_lenb = (opt_len + 3 + 7) >> 3, static_lenb = (static_len + 3 + 7) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;                       /* trees.c:948 */
+    b->hdr_bits = 0;
+    if (b->in_len + 4 <= opt_lenb && (b->flags & ZC_BF_CANSTORE)) {            /* trees.c:958 */
+        b->type = 0; b->bits = 0;
+    } else if (strategy == ZC_STRAT_FIXED || static_lenb == opt_lenb) {        /* trees.c:972 */
+        b->type = 1; b->bits = 3 + static_len;
+        for (uint32_t n = 0; n < 288; n++) tab->lc[n] = zc_static_lcode(n);
+        for (uint32_t n = 0; n < 30; n++) tab->dc[n] = zc_static_dcode(n);
+    } else {
+        b->type = 2; b->bits = 3 + opt_len;
+        zc_assign_codes(lt, tab->lc, 288);
+        zc_assign_codes(dt, tab->dc, 32);
+        uint32_t bltab[ZC_BL_CODES];
+        zc_assign_codes(bt, bltab, ZC_BL_CODES);
+        for (int i = 0; i < ZC_HDR_BYTES; i++) tab->hdr[i] = 0;
+        ZcBitW w; w.buf = tab->hdr; w.nbits = 0;
+        /* send_all_trees, trees.c:836-860 */
+        w.put((uint32_t)(lt.max_code + 1 - 257), 5);
+        w.put((uint32_t)(dt.max_code + 1 - 1), 5);
+        w.put((uint32_t)(max_bl + 1 - 4), 4);
+        for (int r = 0; r <= max_bl; r++) w.put(bt.len[bl_order[r]], 3);
+        zc_walk_lengths([&](int n) { return lt.len[n]; }, lt.max_code, nullptr, bltab, &w);
+        zc_walk_lengths([&](int n) { return dt.len[n]; }, dt.max_code, nullptr, bltab, &w);
+        b->hdr_bits = w.nbits;
+    }
+}
+
+/* Bit layout of one chunk: walks the block table, assigns bit offsets relative
+ * to the chunk start and returns the chunk's byte length.  Stored blocks pad to
+ * a byte boundary after their 3 header bits (copy_block, trees.c:1205-1219);
+ * a non-final chunk ends with the empty stored block of Z_SYNC_FLUSH
+ * (deflate.c:926-927), a final one is padded by bi_windup (trees.c:996-1001). */
+template <class BlkAt>
+ZC_HD uint64_t zc_layout_chunk(BlkAt blk_at, uint32_t nblk, uint32_t final_, uint64_t *sync_bit_off)
+{
+    uint64_t bit = 0;
+    for (uint32_t i = 0; i < nblk; i++) {
+        ZcBlock *b = blk_at(i);
+        b->bit_off = bit;
+        if (b->type == 0) { bit += 3; bit = (bit + 7) & ~7ull; bit += 32 + 8ull * b->in_len; }
+        else bit += b->bits;
+    }
+    if (final_) bit = (bit + 7) & ~7ull;
+    else { *sync_bit_off = bit; bit += 3; bit = (bit + 7) & ~7ull; bit += 32; }
+    return bit >> 3;
+}
+
+#endif /* ZAMD_CORE_H */

@@ -1,0 +1,854 @@
+/*
+ * zamd_engine.hip — HIP kernels (gfx950) and host orchestration of the chunked
+ * DEFLATE engine.  C ABI in include/zamd.h; per-lane logic in zamd_core.h.
+ *
+ * Pipeline for levels 4-9 (one batch of chunks per pass, two batches in flight
+ * on two streams):
+ *   k_chain   hash-chain build: INSERT_STRING for every position, head table in
+ *             LDS, writes the distance to the previous same-hash string
+ *   k_match   longest_match for every position ahead of the parse; window bytes
+ *             and chain links of a 16 Ki-position tile (+32 KiB halo) staged in LDS
+ *   k_parse   deflate_slow lazy evaluation replayed over the match records in
+ *             exact reference order; symbol stream + block table (lit_bufsize rule)
+ *   k_plan    per block: _tr_tally histograms with LDS atomics, build_tree x3,
+ *             stored/static/dynamic choice, code tables, header bits
+ *   k_layout  per chunk bit layout, k_scan exclusive scan -> output offsets
+ *   k_emit    compress_block: prefix sums over code lengths, LDS bit staging,
+ *             OR into the zeroed output
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include "zamd_core.h"
+#include "../../include/zamd.h"
+
+#define ZK_TILE      16384u                   /* positions per k_match workgroup */
+#define ZK_HALO      32768u
+#define ZK_WIN_BYTES (ZK_HALO + ZK_TILE + 320u)
+#define ZK_MATCH_THREADS 1024
+#define ZK_PLAN_THREADS  256
+#define ZK_EMIT_THREADS  256
+#define ZK_STAGE_WORDS   400                  /* 31 + 256*48 + 31 bits */
+
+enum { ZE_CHAIN_ORDER = 1, ZE_BLOCK_OVERFLOW = 2, ZE_OUT_OVERFLOW = 4, ZE_INFLATE_DATA = 8 };
+
+struct ZkJob {
+    const uint8_t *in; uint64_t n;
+    uint64_t chunk0; uint32_t nchunks; int finish;
+    ZcParams P;
+    uint16_t *pdist; uint64_t pdist_base, pdist_len;
+    uint2 *rec; uint64_t rec_base;
+    uint32_t *sym;
+    ZcBlock *blk; ZcBlockTab *tab;
+    uint32_t *nblk; uint32_t *nsym;
+    uint64_t *chunk_bytes; uint64_t *sync_bit;
+    uint64_t *chunk_off;          /* global table, indexed by absolute chunk number */
+    uint64_t *running_total;      /* bytes written by earlier batches */
+    uint32_t *out32; uint64_t out_cap;
+    uint32_t *err;
+};
+
+/* ------------------------------------------------------------------ k_chain */
+__global__ __launch_bounds__(64) void k_chain(ZkJob J)
+{
+    __shared__ uint32_t head[32768];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t c = J.chunk0 + blockIdx.x;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish);
+    const uint32_t E = g.dict_len + g.len;
+    /* positions with three bytes available in the whole input */
+    uint64_t avail = J.n - g.dstart;
+    uint32_t Ex = E;
+    if ((uint64_t)E + 2 > avail) Ex = avail >= 2 ? (uint32_t)(avail - 2) : 0;
+    const uint32_t out_from = blockIdx.x == 0 ? 0u : g.dict_len;
+    const uint8_t *src = J.in + g.dstart;
+    uint16_t *pd = J.pdist + (g.dstart - J.pdist_base);
+    const uint32_t passes = J.P.hash_bits > 15 ? (1u << (J.P.hash_bits - 15)) : 1u;
+    for (uint32_t pass = 0; pass < passes; pass++) {
+        for (uint32_t i = lane; i < 32768; i += 64) head[i] = 0;
+        __syncthreads();
+        for (uint32_t a0 = 0; a0 < Ex; a0 += 64) {
+            uint32_t a = a0 + lane;
+            bool valid = a < Ex;
+            uint32_t h = 0;
+            if (valid) h = zc_hash3(src[a], src[a + 1], src[a + 2], J.P.hash_shift, J.P.hash_mask);
+            bool mine = valid && (h >> 15) == pass;
+            uint32_t old = 0;
+            /* LDS atomic max: lanes hold increasing positions, so the value returned
+             * to a lane is the newest earlier string with the same hash */
+            if (mine) old = atomicMax(&head[h & 32767u], a + 1);
+            if (mine) {
+                if (old > a) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
+                uint32_t d = old ? a + 1 - old : 0;
+                if (d > 32767u) d = 0;
+                if (a >= out_from) pd[a] = (uint16_t)d;
+            }
+        }
+        __syncthreads();
+    }
+    /* strings without three bytes of input are never inserted */
+    for (uint32_t a = Ex + lane; a < E; a += 64) if (a >= out_from) pd[a] = 0;
+}
+
+/* ------------------------------------------------------------------ k_match */
+struct LdsWin {
+    const uint32_t *w; uint32_t a0;
+    __device__ uint32_t load4(uint32_t a) const
+    {
+        uint32_t off = a - a0, i = off >> 2;
+        return __builtin_amdgcn_alignbyte(w[i + 1], w[i], off & 3u);
+    }
+};
+struct LdsPd {
+    const uint16_t *pd; uint32_t a0;
+    __device__ uint32_t operator()(uint32_t a) const { return pd[a - a0]; }
+};
+
+__global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t tiles_per_chunk, int rle)
+{
+    __shared__ uint32_t s_win[ZK_WIN_BYTES / 4];
+    __shared__ uint16_t s_pd[ZK_HALO + ZK_TILE];
+    __shared__ uint32_t s_next;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    if ((uint64_t)tile * ZK_TILE >= g.len) return;
+    const uint32_t E = g.dict_len + g.len;
+    const uint32_t t0 = g.dict_len + tile * ZK_TILE;
+    const uint32_t tlen = (E - t0) < ZK_TILE ? (E - t0) : ZK_TILE;
+    const int64_t a0 = (int64_t)t0 - (int64_t)ZK_HALO;      /* a-coordinate of LDS byte 0 */
+    /* window bytes */
+    for (uint32_t v = tid; v < ZK_WIN_BYTES / 16; v += ZK_MATCH_THREADS) {
+        int64_t a = a0 + 16 * (int64_t)v;
+        int64_t abs = (int64_t)g.dstart + a;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (a >= 0 && (uint64_t)abs + 16 <= J.n) q = *(const uint4 *)(J.in + abs);
+        else if (a + 16 > 0 && abs < (int64_t)J.n) {
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++) {
+                int64_t ak = a + k, absk = abs + k;
+                if (ak >= 0 && absk < (int64_t)J.n) t[k >> 2] |= (uint32_t)J.in[absk] << (8 * (k & 3));
+            }
+            q = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        ((uint4 *)s_win)[v] = q;
+    }
+    if (!rle) {
+        for (uint32_t v = tid; v < (ZK_HALO + ZK_TILE) / 8; v += ZK_MATCH_THREADS) {
+            int64_t a = a0 + 8 * (int64_t)v;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (a >= 0) {
+                uint64_t idx = g.dstart + (uint64_t)a - J.pdist_base;
+                if (idx + 8 <= J.pdist_len) q = *(const uint4 *)(J.pdist + idx);
+            }
+            ((uint4 *)s_pd)[v] = q;
+        }
+    }
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    LdsWin win; win.w = s_win; win.a0 = (uint32_t)a0;
+    LdsPd pd; pd.pd = s_pd; pd.a0 = (uint32_t)a0;
+    uint2 *rec = J.rec + (g.dstart + t0 - J.rec_base);
+    const uint32_t lane = tid & 63u;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_next, 64u);
+        base = __shfl(base, 0);
+        if (base >= tlen) break;
+        uint32_t i = base + lane;
+        if (i < tlen) {
+            uint32_t rf, rq;
+            if (rle) { rf = zc_rle_pos(win, t0 + i, E); rq = rf; }
+            else zc_match_pos(win, pd, t0 + i, E, g.corner, J.P.nice, J.P.chain, &rf, &rq);
+            rec[i] = make_uint2(rf, rq);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ k_parse */
+struct GRec {
+    const uint2 *r;               /* indexed by a - dict_len */
+    uint32_t dict_len;
+    __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q) const { uint2 v = r[p - dict_len]; *f = v.x; *q = v.y; }
+};
+struct GSym { uint32_t *s; __device__ void operator()(uint32_t i, uint32_t w) const { s[i] = w; } };
+struct GBlk {
+    ZcBlock *b; uint32_t cap; uint32_t *err;
+    __device__ void operator()(uint32_t i, const ZcBlock &v) const { if (i < cap) b[i] = v; else atomicOr(err, (uint32_t)ZE_BLOCK_OVERFLOW); }
+};
+
+__global__ __launch_bounds__(64) void k_parse(ZkJob J)
+{
+    uint32_t lc = blockIdx.x * 64 + threadIdx.x;
+    if (lc >= J.nchunks) return;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    GRec rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
+    GSym sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size;
+    GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err;
+    uint32_t nsym = 0, nb;
+    if (J.P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, J.P, blk);
+    else if (J.P.parser == ZC_PARSE_RLE) nb = zc_parse_rle(g.dict_len, g.len, g.final, J.P, rec, sym, blk, &nsym);
+    else nb = zc_parse_slow(g.dict_len, g.len, g.final, J.P, rec, sym, blk, &nsym);
+    J.nblk[lc] = nb < J.P.max_blocks ? nb : J.P.max_blocks;
+    J.nsym[lc] = nsym;
+}
+
+/* ------------------------------------------------------------------ k_plan */
+__global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
+{
+    __shared__ ZcTree<ZC_L_CODES> lt;
+    __shared__ ZcTree<ZC_D_CODES> dt;
+    __shared__ ZcTree<ZC_BL_CODES> bt;
+    __shared__ uint32_t hist[288 + 32];
+    __shared__ uint32_t cost[4];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lc = blockIdx.y, j = blockIdx.x;
+    if (j >= J.nblk[lc]) return;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    ZcBlock *bp = J.blk + (uint64_t)lc * J.P.max_blocks + j;
+    ZcBlock b = *bp;
+    const uint8_t *src = J.in + g.dstart;
+    const uint32_t *sym = J.sym + (uint64_t)lc * J.P.chunk_size + b.sym_start;
+    for (uint32_t i = tid; i < 320; i += ZK_PLAN_THREADS) hist[i] = 0;
+    if (tid < 4) cost[tid] = 0;
+    __syncthreads();
+    /* _tr_tally frequency counts (trees.c:1017-1030) */
+    for (uint32_t i = tid; i < b.sym_count; i += ZK_PLAN_THREADS) {
+        if (b.flags & ZC_BF_IMPLICIT) { atomicAdd(&hist[src[b.in_start + i]], 1u); continue; }
+        uint32_t s = sym[i];
+        if (!(s & ZC_SYM_MATCH)) atomicAdd(&hist[src[s]], 1u);
+        else {
+            atomicAdd(&hist[257u + zc_len_code((s >> 16) & 0xffu)], 1u);
+            atomicAdd(&hist[288u + zc_dist_code((s & 0xffffu) - 1u)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ZC_L_CODES; i += ZK_PLAN_THREADS) lt.freq[i] = (uint16_t)(i == ZC_END_BLOCK ? 1u : hist[i]);
+    if (tid < ZC_D_CODES) dt.freq[tid] = (uint16_t)hist[288 + tid];
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t o = 0, s = 0;
+        zc_build_tree(lt, 15, true, [](int n) { return zc_static_llen((uint32_t)n); },
+                      [](int n) { return n >= 257 ? zc_len_extra((uint32_t)n - 257u) : 0u; }, &o, &s);
+        cost[0] = o; cost[1] = s;
+    } else if (tid == 64) {
+        uint32_t o = 0, s = 0;
+        zc_build_tree(dt, 15, true, [](int) { return 5u; },
+                      [](int n) { return zc_dist_extra((uint32_t)n); }, &o, &s);
+        cost[2] = o; cost[3] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ZcBlockTab *tab = J.tab + (uint64_t)lc * J.P.max_blocks + j;
+        zc_plan_block(lt, dt, bt, cost[0] + cost[2], cost[1] + cost[3], J.P.strategy, &b, tab);
+        bp->type = b.type; bp->bits = b.bits; bp->hdr_bits = b.hdr_bits;
+    }
+}
+
+/* ------------------------------------------------------------------ k_layout / k_scan */
+__global__ void k_layout(ZkJob J)
+{
+    uint32_t lc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lc >= J.nchunks) return;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    ZcBlock *base = J.blk + (uint64_t)lc * J.P.max_blocks;
+    uint64_t sync = 0;
+    /* a non-final chunk that is the last of a call without finish still ends on a sync marker */
+    J.chunk_bytes[lc] = zc_layout_chunk([&](uint32_t i) { return base + i; }, J.nblk[lc], g.final, &sync);
+    J.sync_bit[lc] = sync;
+}
+
+__global__ __launch_bounds__(1024) void k_scan(ZkJob J)
+{
+    /* exclusive scan of the batch's chunk sizes on top of the running total */
+    __shared__ uint64_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (J.nchunks + 1023) / 1024;
+    uint64_t sum = 0;
+    for (uint32_t k = 0; k < per; k++) { uint32_t i = tid * per + k; if (i < J.nchunks) sum += J.chunk_bytes[i]; }
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { uint64_t run = *J.running_total; for (uint32_t i = 0; i < 1024; i++) { uint64_t v = part[i]; part[i] = run; run += v; }
+                    *J.running_total = run; J.chunk_off[J.chunk0 + J.nchunks] = run;
+                    if (run > J.out_cap) atomicOr(J.err, (uint32_t)ZE_OUT_OVERFLOW); }
+    __syncthreads();
+    uint64_t run = part[tid];
+    for (uint32_t k = 0; k < per; k++) { uint32_t i = tid * per + k; if (i < J.nchunks) { J.chunk_off[J.chunk0 + i] = run; run += J.chunk_bytes[i]; } }
+}
+
+/* ------------------------------------------------------------------ k_emit */
+__device__ inline void g_or_bits(uint32_t *out32, uint64_t bitpos, uint64_t v, uint32_t n)
+{
+    if (!n) return;
+    uint64_t w = bitpos >> 5; uint32_t sh = (uint32_t)bitpos & 31u;
+    uint32_t w0 = (uint32_t)(v << sh);
+    uint64_t rest = sh ? (v >> (32u - sh)) : (v >> 32);
+    uint32_t w1 = (uint32_t)rest, w2 = (uint32_t)(rest >> 32);
+    if (w0) atomicOr(&out32[w], w0);
+    if (w1) atomicOr(&out32[w + 1], w1);
+    if (w2) atomicOr(&out32[w + 2], w2);
+}
+__device__ inline void lds_or_bits(uint32_t *st, uint32_t bitpos, uint64_t v, uint32_t n)
+{
+    if (!n) return;
+    uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+    uint32_t w0 = (uint32_t)(v << sh);
+    uint64_t rest = sh ? (v >> (32u - sh)) : (v >> 32);
+    uint32_t w1 = (uint32_t)rest, w2 = (uint32_t)(rest >> 32);
+    if (w0) atomicOr(&st[w], w0);
+    if (w1) atomicOr(&st[w + 1], w1);
+    if (w2) atomicOr(&st[w + 2], w2);
+}
+
+__global__ __launch_bounds__(ZK_EMIT_THREADS) void k_emit(ZkJob J)
+{
+    __shared__ uint32_t stage[ZK_STAGE_WORDS];
+    __shared__ uint32_t wsum[ZK_EMIT_THREADS / 64];
+    __shared__ uint32_t ltab[288], dtab[32];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t lc = blockIdx.y, j = blockIdx.x;
+    if (*J.err) return;
+    const uint32_t nb = J.nblk[lc];
+    if (j > nb) return;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    const uint64_t cbit = J.chunk_off[J.chunk0 + lc] * 8ull;
+    uint32_t *out32 = J.out32;
+    if (j == nb) {                                /* Z_SYNC_FLUSH marker: 000, pad, 00 00 FF FF */
+        if (!g.final && tid == 0) {
+            uint64_t bit = cbit + J.sync_bit[lc] + 3;
+            bit = (bit + 7) & ~7ull;
+            g_or_bits(out32, bit + 16, 0xffffu, 16);
+        }
+        return;
+    }
+    const ZcBlock b = J.blk[(uint64_t)lc * J.P.max_blocks + j];
+    const uint8_t *src = J.in + g.dstart;
+    const uint64_t bit0 = cbit + b.bit_off;
+    const uint32_t last = b.flags & ZC_BF_LAST;
+    if (b.type == 0) {                            /* _tr_stored_block, trees.c:865-877 */
+        uint64_t byte = ((bit0 + 3 + 7) >> 3);
+        if (tid == 0) {
+            g_or_bits(out32, bit0, last, 3);
+            uint32_t l = b.in_len & 0xffffu;
+            g_or_bits(out32, byte * 8, l | ((~l & 0xffffu) << 16), 32);
+        }
+        byte += 4;
+        for (uint32_t i = tid * 4; i < b.in_len; i += ZK_EMIT_THREADS * 4) {
+            uint32_t v = 0, k = 0;
+            for (; k < 4 && i + k < b.in_len; k++) v |= (uint32_t)src[b.in_start + i + k] << (8 * k);
+            g_or_bits(out32, (byte + i) * 8, v, 8 * k);
+        }
+        return;
+    }
+    const ZcBlockTab *tab = J.tab + (uint64_t)lc * J.P.max_blocks + j;
+    for (uint32_t i = tid; i < 288; i += ZK_EMIT_THREADS) ltab[i] = tab->lc[i];
+    if (tid < 32) dtab[tid] = tab->dc[tid];
+    /* block header: 3 type bits, then the dynamic tree description (send_all_trees) */
+    if (tid == 0) g_or_bits(out32, bit0, (b.type << 1) | last, 3);
+    for (uint32_t i = tid; i * 32 < b.hdr_bits; i += ZK_EMIT_THREADS) {
+        uint32_t nbits = b.hdr_bits - i * 32 < 32 ? b.hdr_bits - i * 32 : 32;
+        uint32_t v = (uint32_t)tab->hdr[4 * i] | ((uint32_t)tab->hdr[4 * i + 1] << 8) |
+                     ((uint32_t)tab->hdr[4 * i + 2] << 16) | ((uint32_t)tab->hdr[4 * i + 3] << 24);
+        if (nbits < 32) v &= (1u << nbits) - 1u;
+        g_or_bits(out32, bit0 + 3 + i * 32, v, nbits);
+    }
+    __syncthreads();
+    const uint32_t *sym = J.sym + (uint64_t)lc * J.P.chunk_size + b.sym_start;
+    uint64_t bitpos = bit0 + 3 + b.hdr_bits;
+    const uint32_t total = b.sym_count + 1;       /* + END_BLOCK */
+    for (uint32_t t = 0; t < total; t += ZK_EMIT_THREADS) {
+        uint32_t i = t + tid;
+        uint64_t v = 0; uint32_t n = 0;
+        if (i < b.sym_count) {
+            uint32_t s, lit = 0;
+            if (b.flags & ZC_BF_IMPLICIT) { s = 0; lit = src[b.in_start + i]; }
+            else { s = sym[i]; if (!(s & ZC_SYM_MATCH)) lit = src[s]; }
+            n = zc_sym_bits(s, lit, ltab, dtab, &v);
+        } else if (i == b.sym_count) { v = ltab[ZC_END_BLOCK] & 0xffffu; n = ltab[ZC_END_BLOCK] >> 16; }
+        /* exclusive prefix sum of code lengths over the 256-symbol tile */
+        uint32_t incl = n;
+        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) wsum[wv] = incl;
+        for (uint32_t k = tid; k < ZK_STAGE_WORDS; k += ZK_EMIT_THREADS) stage[k] = 0;
+        __syncthreads();
+        uint32_t woff = 0, tile_bits = 0;
+        for (uint32_t k = 0; k < ZK_EMIT_THREADS / 64; k++) { uint32_t ws = wsum[k]; if (k < wv) woff += ws; tile_bits += ws; }
+        const uint32_t sh = (uint32_t)bitpos & 31u;
+        lds_or_bits(stage, sh + woff + incl - n, v, n);
+        __syncthreads();
+        const uint32_t nwords = (sh + tile_bits + 31) >> 5;
+        const uint64_t w0 = bitpos >> 5;
+        for (uint32_t k = tid; k < nwords; k += ZK_EMIT_THREADS) { uint32_t x = stage[k]; if (x) atomicOr(&out32[w0 + k], x); }
+        bitpos += tile_bits;
+        __syncthreads();
+    }
+}
+
+/* ------------------------------------------------------------------ checksums
+ * adler32 (adler32.c:65-133) and crc32 (crc32.c:204-278) of one slice per
+ * workgroup.  Each lane reduces a contiguous sub-slice; partial results are
+ * merged with the combine identities (adler32.c:136, crc32.c:355). */
+#define ZK_CRC_POLY 0xedb88320u
+__device__ __host__ inline uint32_t gf2_mul(uint32_t a, uint32_t b)
+{   /* product of two polynomials mod the CRC polynomial, bit 31 = x^0 */
+    uint32_t p = 0;
+    for (uint32_t m = 0x80000000u; m; m >>= 1) {
+        if (a & m) p ^= b;
+        b = (b & 1u) ? (b >> 1) ^ ZK_CRC_POLY : b >> 1;
+    }
+    return p;
+}
+__device__ __host__ inline uint32_t gf2_xpow8n(uint64_t nbytes, const uint32_t *x2n)
+{   /* x^(8*nbytes); x2n[k] = x^(2^k) */
+    uint32_t p = 0x80000000u; uint32_t k = 3;
+    while (nbytes) { if (nbytes & 1u) p = gf2_mul(x2n[k & 63u], p); nbytes >>= 1; k++; }
+    return p;
+}
+struct ZkCrcConst { uint32_t tab[256]; uint32_t x2n[64]; };
+__constant__ ZkCrcConst c_crc;
+static ZkCrcConst h_crc; static bool h_crc_ready = false;
+static void crc_host_init()
+{
+    if (h_crc_ready) return;
+    for (uint32_t n = 0; n < 256; n++) { uint32_t c = n; for (int k = 0; k < 8; k++) c = (c & 1u) ? ZK_CRC_POLY ^ (c >> 1) : c >> 1; h_crc.tab[n] = c; }
+    uint32_t p = 0x40000000u;                     /* x^1 */
+    h_crc.x2n[0] = p;
+    for (int k = 1; k < 64; k++) { p = gf2_mul(p, p); h_crc.x2n[k] = p; }
+    h_crc_ready = true;
+}
+
+__global__ __launch_bounds__(256) void k_checksum(const uint8_t *in, uint64_t n, uint32_t slice, uint32_t *adler_out, uint32_t *crc_out)
+{
+    __shared__ uint32_t s_tab[256];
+    __shared__ unsigned long long s_a[256], s_w[256];
+    __shared__ uint32_t s_c[256];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t start = (uint64_t)blockIdx.x * slice;
+    const uint32_t L = (uint32_t)((n - start) < slice ? (n - start) : slice);
+    const uint8_t *p = in + start;
+    s_tab[tid] = c_crc.tab[tid];
+    __syncthreads();
+    uint32_t seg = (L + 255) / 256; seg = (seg + 15) & ~15u;
+    uint32_t b0 = tid * seg, b1 = b0 + seg; if (b0 > L) b0 = L; if (b1 > L) b1 = L;
+    unsigned long long A = 0, W = 0; uint32_t crc = 0;
+    for (uint32_t o = b0; o < b1; ) {
+        if (o + 16 <= b1 && (((uintptr_t)(p + o)) & 15u) == 0) {
+            uint4 q = *(const uint4 *)(p + o);
+            uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t sb = 0, sj = 0;
+            for (int k = 0; k < 4; k++) {
+                uint32_t x = w[k];
+                uint32_t y0 = x & 0xff, y1 = (x >> 8) & 0xff, y2 = (x >> 16) & 0xff, y3 = x >> 24;
+                sb += y0 + y1 + y2 + y3;
+                sj += (4 * k) * y0 + (4 * k + 1) * y1 + (4 * k + 2) * y2 + (4 * k + 3) * y3;
+                crc ^= x;
+                crc = s_tab[crc & 0xff] ^ (crc >> 8); crc = s_tab[crc & 0xff] ^ (crc >> 8);
+                crc = s_tab[crc & 0xff] ^ (crc >> 8); crc = s_tab[crc & 0xff] ^ (crc >> 8);
+            }
+            A += sb; W += (unsigned long long)(L - o) * sb - sj;
+            o += 16;
+        } else {
+            uint32_t y = p[o];
+            A += y; W += (unsigned long long)(L - o) * y;
+            crc = s_tab[(crc ^ y) & 0xff] ^ (crc >> 8);
+            o++;
+        }
+    }
+    /* shift this lane's raw CRC over the bytes that follow it */
+    crc = gf2_mul(gf2_xpow8n(L - b1, c_crc.x2n), crc);
+    s_a[tid] = A; s_w[tid] = W; s_c[tid] = crc;
+    __syncthreads();
+    for (uint32_t d = 128; d; d >>= 1) {
+        if (tid < d) { s_a[tid] += s_a[tid + d]; s_w[tid] += s_w[tid + d]; s_c[tid] ^= s_c[tid + d]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (adler_out) {
+            uint32_t s1 = (uint32_t)((1ull + s_a[0]) % 65521ull);
+            uint32_t s2 = (uint32_t)(((unsigned long long)L + s_w[0]) % 65521ull);
+            adler_out[blockIdx.x] = s1 | (s2 << 16);
+        }
+        if (crc_out) crc_out[blockIdx.x] = gf2_mul(gf2_xpow8n(L, c_crc.x2n), 0xffffffffu) ^ s_c[0] ^ 0xffffffffu;
+    }
+}
+
+/* ------------------------------------------------------------------ host side */
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "zamd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), __FILE__, __LINE__); return ZAMD_HIP_ERROR(_e); } } while (0)
+
+struct ZeWorkspace {
+    uint32_t cap_chunks = 0, chunk_size = 0, max_blocks = 0;
+    uint16_t *pdist = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr;
+    ZcBlock *blk = nullptr; ZcBlockTab *tab = nullptr;
+    uint32_t *nblk = nullptr, *nsym = nullptr; uint64_t *chunk_bytes = nullptr, *sync_bit = nullptr;
+    uint64_t pdist_len = 0;
+};
+
+struct zamd_engine {
+    int device;
+    hipStream_t st[2];
+    hipEvent_t ev_scan[2];
+    ZeWorkspace ws[2];
+    uint64_t ws_budget;
+    uint64_t *d_total; uint32_t *d_err;
+    uint64_t *d_off_own; uint64_t d_off_cap;
+    /* timing */
+    hipEvent_t ev_call[2];
+    struct Tm { hipEvent_t a, b; int which; };
+    Tm *tm; int n_tm, cap_tm;
+    double t_ms[8]; int t_n[8];
+    /* last job for debugging */
+    ZkJob last_job; bool have_last;
+    uint32_t *d_ck_a, *d_ck_c; uint64_t ck_cap;
+};
+
+static void ws_free(ZeWorkspace &w)
+{
+    hipFree(w.pdist); hipFree(w.rec); hipFree(w.sym); hipFree(w.blk); hipFree(w.tab);
+    hipFree(w.nblk); hipFree(w.nsym); hipFree(w.chunk_bytes); hipFree(w.sync_bit);
+    w = ZeWorkspace();
+}
+
+static uint64_t ws_bytes_per_chunk(uint32_t chunk_size, uint32_t max_blocks)
+{
+    return 2ull * chunk_size + 8ull * chunk_size + 4ull * chunk_size +
+           (uint64_t)max_blocks * (sizeof(ZcBlock) + sizeof(ZcBlockTab)) + 64;
+}
+
+static int ws_ensure(ZeWorkspace &w, uint32_t chunks, uint32_t chunk_size, uint32_t max_blocks)
+{
+    if (w.cap_chunks >= chunks && w.chunk_size == chunk_size && w.max_blocks == max_blocks) return 0;
+    ws_free(w);
+    w.pdist_len = (uint64_t)chunks * chunk_size + ZC_WSIZE + 64;
+    HIPCHK(hipMalloc((void **)&w.pdist, w.pdist_len * 2));
+    HIPCHK(hipMalloc((void **)&w.rec, (uint64_t)chunks * chunk_size * 8));
+    HIPCHK(hipMalloc((void **)&w.sym, (uint64_t)chunks * chunk_size * 4));
+    HIPCHK(hipMalloc((void **)&w.blk, (uint64_t)chunks * max_blocks * sizeof(ZcBlock)));
+    HIPCHK(hipMalloc((void **)&w.tab, (uint64_t)chunks * max_blocks * sizeof(ZcBlockTab)));
+    HIPCHK(hipMalloc((void **)&w.nblk, (uint64_t)chunks * 4));
+    HIPCHK(hipMalloc((void **)&w.nsym, (uint64_t)chunks * 4));
+    HIPCHK(hipMalloc((void **)&w.chunk_bytes, (uint64_t)chunks * 8));
+    HIPCHK(hipMalloc((void **)&w.sync_bit, (uint64_t)chunks * 8));
+    w.cap_chunks = chunks; w.chunk_size = chunk_size; w.max_blocks = max_blocks;
+    return 0;
+}
+
+extern "C" const char *zamd_version(void) { return "zlib_amd 0.1 (deflate semantics of zlib 1.2.8)"; }
+
+extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t workspace_bytes)
+{
+    if (!out) return ZAMD_STREAM_ERROR;
+    int count = 0;
+    hipError_t ce = hipGetDeviceCount(&count);
+    if (ce != hipSuccess || count <= 0) {
+        fprintf(stderr, "zamd: no HIP device available (%s); this library has no CPU path\n", hipGetErrorString(ce));
+        return ZAMD_HIP_ERROR(ce == hipSuccess ? hipErrorNoDevice : ce);
+    }
+    HIPCHK(hipSetDevice(device));
+    zamd_engine *e = new (std::nothrow) zamd_engine();
+    if (!e) return ZAMD_MEM_ERROR;
+    memset((void *)e, 0, sizeof *e);
+    for (int i = 0; i < 2; i++) e->ws[i] = ZeWorkspace();
+    e->device = device;
+    e->ws_budget = workspace_bytes ? workspace_bytes : (48ull << 30);
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipStreamCreateWithFlags(&e->st[i], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_scan[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&e->ev_call[i]));
+    }
+    HIPCHK(hipMalloc((void **)&e->d_total, 8));
+    HIPCHK(hipMalloc((void **)&e->d_err, 4));
+    crc_host_init();
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_crc), &h_crc, sizeof h_crc));
+    e->cap_tm = 512; e->tm = (zamd_engine::Tm *)calloc((size_t)e->cap_tm, sizeof(zamd_engine::Tm));
+    for (int i = 0; i < e->cap_tm; i++) { HIPCHK(hipEventCreate(&e->tm[i].a)); HIPCHK(hipEventCreate(&e->tm[i].b)); }
+    *out = e;
+    return ZAMD_OK;
+}
+
+extern "C" void zamd_engine_destroy(zamd_engine *e)
+{
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    for (int i = 0; i < 2; i++) { ws_free(e->ws[i]); hipStreamDestroy(e->st[i]); hipEventDestroy(e->ev_scan[i]); hipEventDestroy(e->ev_call[i]); }
+    for (int i = 0; i < e->cap_tm; i++) { hipEventDestroy(e->tm[i].a); hipEventDestroy(e->tm[i].b); }
+    free(e->tm);
+    hipFree(e->d_total); hipFree(e->d_err); hipFree(e->d_off_own); hipFree(e->d_ck_a); hipFree(e->d_ck_c);
+    delete e;
+}
+
+static uint32_t max_blocks_for(uint32_t chunk_size, int mem_level)
+{
+    uint32_t lim = (1u << (mem_level + 6)) - 1;
+    return (chunk_size + lim - 1) / lim + 2;
+}
+
+extern "C" uint64_t zamd_deflate_bound(uint64_t n, uint32_t chunk_size, int mem_level)
+{
+    if (chunk_size == 0 || mem_level < 1 || mem_level > 9) return 0;
+    uint64_t chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
+    /* worst case: every block stored (5 bytes each, and never larger than the
+     * coded form + 4) plus the sync marker / final padding per chunk */
+    uint64_t b = n + chunks * ((uint64_t)max_blocks_for(chunk_size, mem_level) * 5 + 16) + 64;
+    return (b + 15) & ~15ull;
+}
+
+static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint32_t chunk_size)
+{
+    static const uint16_t cfg[10][4] = {{0, 0, 0, 0}, {4, 4, 8, 4}, {4, 5, 16, 8}, {4, 6, 32, 32}, {4, 4, 16, 16},
+                                        {8, 16, 32, 32}, {8, 16, 128, 128}, {8, 32, 128, 256}, {32, 128, 258, 1024}, {32, 258, 258, 4096}};
+    if (level == -1) level = 6;
+    if (level < 1 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9) return ZAMD_STREAM_ERROR;
+    if (chunk_size < 32768 || chunk_size % 16384 != 0 || chunk_size > (64u << 20)) return ZAMD_STREAM_ERROR;
+    memset(&P, 0, sizeof P);
+    P.level = (uint32_t)level; P.strategy = (uint32_t)strategy; P.mem_level = (uint32_t)mem_level;
+    P.good = cfg[level][0]; P.lazy = cfg[level][1]; P.nice = cfg[level][2]; P.chain = cfg[level][3];
+    P.hash_bits = (uint32_t)mem_level + 7; P.hash_mask = (1u << P.hash_bits) - 1; P.hash_shift = (P.hash_bits + 2) / 3;
+    P.lit_bufsize = 1u << (mem_level + 6);
+    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level <= 3 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
+    P.chunk_size = chunk_size;
+    P.max_blocks = max_blocks_for(chunk_size, mem_level);
+    return ZAMD_OK;
+}
+
+static void tm_begin(zamd_engine *e, hipStream_t s, int which, int *slot)
+{
+    *slot = -1;
+    if (e->n_tm >= e->cap_tm) return;
+    *slot = e->n_tm++;
+    e->tm[*slot].which = which;
+    hipEventRecord(e->tm[*slot].a, s);
+}
+static void tm_end(zamd_engine *e, hipStream_t s, int slot) { if (slot >= 0) hipEventRecord(e->tm[slot].b, s); }
+
+extern "C" int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chunk_size,
+                                int level, int strategy, int mem_level, int finish,
+                                void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out)
+{
+    if (!e || !d_out || (!d_in && n)) return ZAMD_STREAM_ERROR;
+    if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
+    ZcParams P;
+    int rc = fill_params(P, level, strategy, mem_level, chunk_size);
+    if (rc) return rc;
+    if (P.parser == ZC_PARSE_FAST) {
+        fprintf(stderr, "zamd: levels 1-3 (deflate_fast) are not implemented on the GPU yet\n");
+        return ZAMD_STREAM_ERROR;
+    }
+    out_cap &= ~15ull;
+    HIPCHK(hipSetDevice(e->device));
+    const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
+    /* batch size from the workspace budget, two batches in flight */
+    uint64_t per = ws_bytes_per_chunk(chunk_size, P.max_blocks);
+    uint64_t bc = e->ws_budget / 2 / per;
+    if (bc < 1) bc = 1;
+    if (bc > total_chunks) bc = total_chunks;
+    if (total_chunks > bc && total_chunks < 2 * bc) bc = (total_chunks + 1) / 2;
+    if (bc > 0x7fffffu) bc = 0x7fffffu;
+    const uint32_t batch = (uint32_t)bc;
+    const uint32_t nbatches = (uint32_t)((total_chunks + batch - 1) / batch);
+    for (int i = 0; i < (nbatches > 1 ? 2 : 1); i++) { rc = ws_ensure(e->ws[i], batch, chunk_size, P.max_blocks); if (rc) return rc; }
+    uint64_t *d_off = d_chunk_off;
+    if (!d_off) {
+        if (e->d_off_cap < total_chunks + 1) { hipFree(e->d_off_own); e->d_off_own = nullptr; e->d_off_cap = 0;
+            HIPCHK(hipMalloc((void **)&e->d_off_own, (total_chunks + 1) * 8)); e->d_off_cap = total_chunks + 1; }
+        d_off = e->d_off_own;
+    }
+    e->n_tm = 0; e->have_last = false;
+    hipStream_t s0 = e->st[0];
+    HIPCHK(hipEventRecord(e->ev_call[0], s0));
+    HIPCHK(hipMemsetAsync(e->d_total, 0, 8, s0));
+    HIPCHK(hipMemsetAsync(e->d_err, 0, 4, s0));
+    HIPCHK(hipMemsetAsync(d_out, 0, out_cap, s0));
+    HIPCHK(hipEventRecord(e->ev_scan[1], s0));          /* batch 0's predecessor "scan" */
+    const uint32_t tiles = (chunk_size + ZK_TILE - 1) / ZK_TILE;
+    for (uint32_t bi = 0; bi < nbatches; bi++) {
+        const int si = (int)(bi & 1u);
+        hipStream_t s = e->st[si];
+        ZeWorkspace &w = e->ws[si];
+        ZkJob J; memset(&J, 0, sizeof J);
+        J.in = (const uint8_t *)d_in; J.n = n; J.chunk0 = (uint64_t)bi * batch;
+        J.nchunks = (uint32_t)((total_chunks - J.chunk0) < batch ? (total_chunks - J.chunk0) : batch);
+        J.finish = finish; J.P = P;
+        ZcChunkGeom g0 = zc_geom(n, chunk_size, J.chunk0, finish);
+        J.pdist = w.pdist; J.pdist_base = g0.dstart; J.pdist_len = w.pdist_len;
+        J.rec = w.rec; J.rec_base = J.chunk0 * chunk_size;
+        J.sym = w.sym; J.blk = w.blk; J.tab = w.tab; J.nblk = w.nblk; J.nsym = w.nsym;
+        J.chunk_bytes = w.chunk_bytes; J.sync_bit = w.sync_bit;
+        J.chunk_off = d_off; J.running_total = e->d_total;
+        J.out32 = (uint32_t *)d_out; J.out_cap = out_cap; J.err = e->d_err;
+        int slot;
+        if (bi == 1) HIPCHK(hipStreamWaitEvent(s, e->ev_scan[1], 0));   /* memsets on stream 0 */
+        if (P.parser == ZC_PARSE_SLOW) {
+            tm_begin(e, s, 0, &slot);
+            hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(64), 0, s, J);
+            tm_end(e, s, slot);
+        }
+        if (P.parser == ZC_PARSE_SLOW || P.parser == ZC_PARSE_RLE) {
+            tm_begin(e, s, 1, &slot);
+            hipLaunchKernelGGL(k_match, dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles, P.parser == ZC_PARSE_RLE ? 1 : 0);
+            tm_end(e, s, slot);
+        }
+        tm_begin(e, s, 2, &slot);
+        hipLaunchKernelGGL(k_parse, dim3((J.nchunks + 63) / 64), dim3(64), 0, s, J);
+        tm_end(e, s, slot);
+        tm_begin(e, s, 3, &slot);
+        hipLaunchKernelGGL(k_plan, dim3(P.max_blocks, J.nchunks), dim3(ZK_PLAN_THREADS), 0, s, J);
+        tm_end(e, s, slot);
+        tm_begin(e, s, 4, &slot);
+        hipLaunchKernelGGL(k_layout, dim3((J.nchunks + 255) / 256), dim3(256), 0, s, J);
+        /* output offsets chain from batch to batch through d_total */
+        HIPCHK(hipStreamWaitEvent(s, e->ev_scan[si ^ 1], 0));
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, J);
+        HIPCHK(hipEventRecord(e->ev_scan[si], s));
+        tm_end(e, s, slot);
+        tm_begin(e, s, 5, &slot);
+        hipLaunchKernelGGL(k_emit, dim3(P.max_blocks + 1, J.nchunks), dim3(ZK_EMIT_THREADS), 0, s, J);
+        tm_end(e, s, slot);
+        if (bi == 0) { e->last_job = J; e->have_last = true; }
+    }
+    HIPCHK(hipGetLastError());
+    if (nbatches > 1) { HIPCHK(hipStreamSynchronize(e->st[1])); }
+    HIPCHK(hipEventRecord(e->ev_call[1], s0));
+    HIPCHK(hipStreamSynchronize(s0));
+    uint64_t total = 0; uint32_t err = 0;
+    HIPCHK(hipMemcpy(&total, e->d_total, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&err, e->d_err, 4, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; k++) { e->t_ms[k] = 0; e->t_n[k] = 0; }
+    for (int i = 0; i < e->n_tm; i++) { float ms = 0; if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->t_ms[e->tm[i].which] += ms; e->t_n[e->tm[i].which]++; } }
+    { float ms = 0; if (hipEventElapsedTime(&ms, e->ev_call[0], e->ev_call[1]) == hipSuccess) { e->t_ms[6] = ms; e->t_n[6] = 1; } }
+    if (total_out) *total_out = total;
+    if (err & ZE_OUT_OVERFLOW) return ZAMD_BUF_ERROR;
+    if (err) { fprintf(stderr, "zamd: device reported internal error flags 0x%x\n", err); return ZAMD_STREAM_ERROR; }
+    return ZAMD_OK;
+}
+
+extern "C" double zamd_last_timing_ms(zamd_engine *e, int which, int *launches)
+{
+    if (!e || which < 0 || which > 7) return 0;
+    if (launches) *launches = e->t_n[which];
+    return e->t_ms[which];
+}
+
+extern "C" int64_t zamd_debug_dump(zamd_engine *e, int what, uint32_t chunk, void *host_buf, uint64_t max_elems)
+{
+    if (!e || !e->have_last || chunk >= e->last_job.nchunks) return ZAMD_STREAM_ERROR;
+    const ZkJob &J = e->last_job;
+    ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + chunk, J.finish);
+    uint64_t cnt = 0; const void *src = nullptr; size_t esz = 0;
+    uint32_t nb = 0, ns = 0;
+    hipMemcpy(&nb, J.nblk + chunk, 4, hipMemcpyDeviceToHost);
+    hipMemcpy(&ns, J.nsym + chunk, 4, hipMemcpyDeviceToHost);
+    switch (what) {
+    case 0: src = J.pdist + (g.dstart + g.dict_len - J.pdist_base); cnt = g.len; esz = 2; break;
+    case 1: src = J.rec + (g.dstart + g.dict_len - J.rec_base); cnt = g.len; esz = 8; break;
+    case 2: src = J.sym + (uint64_t)chunk * J.P.chunk_size; cnt = ns; esz = 4; break;
+    case 3: src = J.blk + (uint64_t)chunk * J.P.max_blocks; cnt = nb; esz = sizeof(ZcBlock); break;
+    default: return ZAMD_STREAM_ERROR;
+    }
+    if (cnt > max_elems) cnt = max_elems;
+    if (cnt && hipMemcpy(host_buf, src, cnt * esz, hipMemcpyDeviceToHost) != hipSuccess) return ZAMD_HIP_ERROR(1);
+    return (int64_t)cnt;
+}
+
+/* ------------------------------------------------------------------ checksums (host entry points) */
+extern "C" uint32_t zamd_adler32_combine(uint32_t a1, uint32_t a2, int64_t len2)
+{   /* adler32.c:136-162 */
+    const uint32_t B = 65521u;
+    if (len2 < 0) return 0xffffffffu;
+    uint32_t rem = (uint32_t)(len2 % B), s1 = a1 & 0xffffu, s2 = (uint32_t)(((uint64_t)rem * s1) % B);
+    s1 += (a2 & 0xffffu) + B - 1;
+    s2 += (a1 >> 16) + (a2 >> 16) + B - rem;
+    if (s1 >= B) s1 -= B;
+    if (s1 >= B) s1 -= B;
+    if (s2 >= (B << 1)) s2 -= (B << 1);
+    if (s2 >= B) s2 -= B;
+    return s1 | (s2 << 16);
+}
+
+extern "C" uint32_t zamd_crc32_combine(uint32_t c1, uint32_t c2, int64_t len2)
+{   /* crc32.c:327-408: advance c1 over len2 zero bytes, i.e. multiply by x^(8 len2) */
+    if (len2 <= 0) return c1;
+    crc_host_init();
+    return gf2_mul(gf2_xpow8n((uint64_t)len2, h_crc.x2n), c1) ^ c2;
+}
+
+extern "C" int zamd_checksums_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chunk_size,
+                                  uint32_t *d_adler, uint32_t *d_crc)
+{
+    if (!e || (!d_in && n) || chunk_size == 0) return ZAMD_STREAM_ERROR;
+    if (n == 0) return ZAMD_OK;
+    HIPCHK(hipSetDevice(e->device));
+    uint64_t chunks = (n + chunk_size - 1) / chunk_size;
+    if (chunks > 0x7fffffffull) return ZAMD_STREAM_ERROR;
+    hipLaunchKernelGGL(k_checksum, dim3((uint32_t)chunks), dim3(256), 0, e->st[0], (const uint8_t *)d_in, n, chunk_size, d_adler, d_crc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->st[0]));
+    return ZAMD_OK;
+}
+
+static int whole_checksum(zamd_engine *e, const void *d_in, uint64_t n, int want_crc, uint32_t seed, uint32_t *result)
+{
+    if (!e || !result) return ZAMD_STREAM_ERROR;
+    if (n == 0) { *result = seed; return ZAMD_OK; }
+    const uint32_t slice = 1u << 20;
+    uint64_t chunks = (n + slice - 1) / slice;
+    if (e->ck_cap < chunks) {
+        hipFree(e->d_ck_a); hipFree(e->d_ck_c); e->d_ck_a = e->d_ck_c = nullptr; e->ck_cap = 0;
+        HIPCHK(hipMalloc((void **)&e->d_ck_a, chunks * 4)); HIPCHK(hipMalloc((void **)&e->d_ck_c, chunks * 4)); e->ck_cap = chunks;
+    }
+    int rc = zamd_checksums_dev(e, d_in, n, slice, want_crc ? nullptr : e->d_ck_a, want_crc ? e->d_ck_c : nullptr);
+    if (rc) return rc;
+    uint32_t *h = (uint32_t *)malloc(chunks * 4);
+    if (!h) return ZAMD_MEM_ERROR;
+    HIPCHK(hipMemcpy(h, want_crc ? e->d_ck_c : e->d_ck_a, chunks * 4, hipMemcpyDeviceToHost));
+    uint32_t acc = seed;
+    for (uint64_t i = 0; i < chunks; i++) {
+        int64_t len = (int64_t)((n - i * slice) < slice ? (n - i * slice) : slice);
+        acc = want_crc ? zamd_crc32_combine(acc, h[i], len) : zamd_adler32_combine(acc, h[i], len);
+    }
+    free(h);
+    *result = acc;
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_adler32_dev(zamd_engine *e, uint32_t adler, const void *d_in, uint64_t n, uint32_t *result)
+{ return whole_checksum(e, d_in, n, 0, adler, result); }
+extern "C" int zamd_crc32_dev(zamd_engine *e, uint32_t crc, const void *d_in, uint64_t n, uint32_t *result)
+{ return whole_checksum(e, d_in, n, 1, crc, result); }
+
+extern "C" int zamd_inflate_dev(zamd_engine *, const void *, const uint64_t *, uint64_t, uint32_t, void *, uint64_t, int64_t *)
+{
+    fprintf(stderr, "zamd: batch inflate is not implemented yet\n");
+    return ZAMD_STREAM_ERROR;
+}
+
+/* ------------------------------------------------------------------ device-memory helpers */
+extern "C" int zamd_dev_alloc(zamd_engine *e, uint64_t bytes, void **d_ptr)
+{
+    if (!e || !d_ptr) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    hipError_t r = hipMalloc(d_ptr, bytes ? bytes : 16);
+    return r == hipSuccess ? ZAMD_OK : (r == hipErrorOutOfMemory ? ZAMD_MEM_ERROR : ZAMD_HIP_ERROR(r));
+}
+extern "C" int zamd_dev_free(zamd_engine *e, void *d_ptr)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device)); HIPCHK(hipFree(d_ptr)); return ZAMD_OK;
+}
+extern "C" int zamd_dev_upload(zamd_engine *e, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device)); if (bytes) HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return ZAMD_OK;
+}
+extern "C" int zamd_dev_download(zamd_engine *e, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device)); if (bytes) HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return ZAMD_OK;
+}
+extern "C" int zamd_dev_memset(zamd_engine *e, void *d_dst, int value, uint64_t bytes)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device)); if (bytes) HIPCHK(hipMemset(d_dst, value, bytes)); return ZAMD_OK;
+}
