@@ -65,6 +65,17 @@ int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chun
                      void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out);
 
 /*
+ * The same for one shard of a larger input (multi-GPU sharding by chunk range):
+ * the head_dict_len (0 or 32768) bytes in front of d_in are device-resident too
+ * and are the dictionary of the shard's first chunk, exactly as the previous
+ * 32 KiB are for every later chunk.  Pass finish = 1 only on the shard that
+ * holds the end of the input.
+ */
+int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t head_dict_len, uint32_t chunk_size,
+                           int level, int strategy, int mem_level, int finish,
+                           void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out);
+
+/*
  * Per-chunk checksums of a device buffer: adler32 (adler32.c:65) and crc32
  * (crc32.c:204) of every chunk_size slice, each started from the initial value
  * (1 / 0).  d_adler / d_crc receive n_chunks values (either may be NULL).

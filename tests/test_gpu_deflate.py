@@ -1,0 +1,149 @@
+"""Parity of the HIP engine (through the C ABI) with the CPU oracle and with the
+golden vectors of the reference build.  All integer work: the bar is bit-exact."""
+import json
+import os
+import zlib
+
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "deflate_golden.json")))
+GPU_LEVELS = range(4, 10)   # deflate_slow levels; levels 1-3 are declared unsupported by the engine for now
+
+
+def _gpu(engine, data, **kw):
+    out, offs = engine.deflate_chunks(data, **kw)
+    return out, [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
+
+
+@pytest.mark.parametrize("row", [r for r in GOLD["chunked"] if r["level"] >= 4 or r["strategy"] in (2, 3)],
+                         ids=lambda r: "k%d_L%d_S%d_M%d_n%d" % (r["kind"], r["level"], r["strategy"], r["mem_level"], r["n"]))
+def test_golden_rows_from_reference_build(engine, row):
+    data = O.corpus(row["n"], row["kind"], row["seed"])
+    out, lens = _gpu(engine, data, level=row["level"], strategy=row["strategy"], mem_level=row["mem_level"], chunk_size=row["chunk"])
+    assert lens == row["chunk_len"]
+    assert "%08x" % zlib.crc32(out) == row["out_crc"]
+    off = 0
+    for l, c in zip(lens, row["chunk_crc"]):
+        assert "%08x" % zlib.crc32(out[off:off + l]) == c
+        off += l
+
+
+CASES = []
+for kind in range(5):
+    CASES.append((kind, (1 << 20) + 4321, 6, 0, 8, 1 << 19))
+for lvl in GPU_LEVELS:
+    CASES.append((4, 300000, lvl, 0, 8, 65536))
+for strat in (1, 2, 3, 4):
+    CASES.append((3, 700001, 6, strat, 8, 1 << 18))
+    CASES.append((2, 150000, 9, strat, 8, 65536))
+for mem in (1, 2, 4, 7, 9):
+    CASES.append((4, 400000, 6, 0, mem, 131072))
+# ragged / edge sizes: empty, below MIN_MATCH, around MIN_LOOKAHEAD, block-split boundary, tail-mode slide geometry
+for n in (0, 1, 2, 3, 4, 261, 262, 263, 16383, 16384, 32767, 32768, 32769, 65274, 65277, 65374, 65535, 65536, 65537, 98304 + 32600):
+    CASES.append((0, n, 6, 0, 8, 65536))
+    CASES.append((4, n, 9, 0, 8, 32768))
+
+
+@pytest.mark.parametrize("kind,n,level,strategy,mem,chunk", CASES)
+def test_bit_exact_against_oracle(engine, kind, n, level, strategy, mem, chunk):
+    data = O.corpus(n, kind, 17 + kind)
+    want, wlens = O.deflate_chunked(data, chunk, level, strategy, mem)
+    out, lens = _gpu(engine, data, level=level, strategy=strategy, mem_level=mem, chunk_size=chunk)
+    assert lens == wlens
+    assert out == want
+
+
+def test_pathological_inputs(engine):
+    import random
+    rnd = random.Random(99)
+    inputs = [b"\0" * 300000, b"a" * 70000 + b"b" * 70000, bytes(rnd.getrandbits(8) for _ in range(200000)),
+              (b"abc" * 50000)[:140001], bytes((i * 7) & 0xff for i in range(100000)),
+              bytes(rnd.choice(b"ab") for _ in range(150000))]
+    for per in (1, 2, 3, 5, 258, 259, 300, 32505, 32506, 32507):
+        base = bytes(rnd.getrandbits(8) for _ in range(per))
+        inputs.append((base * (120000 // per + 2))[:120000])
+    for data in inputs:
+        for level in (4, 6, 9):
+            want, wlens = O.deflate_chunked(data, 65536, level, 0, 8)
+            out, lens = _gpu(engine, data, level=level, chunk_size=65536)
+            assert out == want
+
+
+def test_full_size_chunks_round_trip_and_sampled_parity(engine):
+    """BASELINE-sized chunks (1 MiB, 256 of them): size-independent properties over the
+    whole stream, byte parity with the oracle on sampled chunks."""
+    n = 256 << 20
+    import zlib_amd
+    data = bytes(zlib_amd.corpus(n, 4, 5, piece_bytes=16 << 20, threads=8))
+    out, offs = engine.deflate_chunks(data, level=6, chunk_size=1 << 20)
+    assert offs[0] == 0 and all(b > a for a, b in zip(offs, offs[1:])) and offs[-1] == len(out)
+    assert zlib.decompress(out, -15) == data                         # one valid raw deflate stream
+    for c in range(len(offs) - 2):
+        assert out[offs[c + 1] - 4:offs[c + 1]] == b"\x00\x00\xff\xff"  # every non-final chunk ends on a sync marker
+    for c in (0, 1, 77, 128, 255):
+        s = c << 20
+        d = min(32768, s)
+        want = O.deflate_chunk(data[s - d:s + (1 << 20)], d, 1 << 20, 6, 0, 8, final=(c == 255))
+        assert out[offs[c]:offs[c + 1]] == want
+
+
+def test_shard_entry_point_continues_a_stream(engine):
+    """A shard with a 32 KiB leading dictionary produces the same chunks as the
+    whole-buffer call (what each rank of a multi-GPU run computes)."""
+    import ctypes as C
+    n, chunk = 6 * 131072 + 555, 131072
+    data = O.corpus(n, 4, 21)
+    whole, offs = engine.deflate_chunks(data, level=6, chunk_size=chunk)
+    split = 3 * chunk
+    d_in = engine.alloc(n); d_in.upload(data)
+    cap = engine.lib.zamd_deflate_bound(n, chunk, 8)
+    d_out = engine.alloc(cap)
+    tot = C.c_uint64(0)
+    rc = engine.lib.zamd_deflate_shard_dev(engine.handle, d_in.ptr, split, 0, chunk, 6, 0, 8, 0, d_out.ptr, cap, None, C.byref(tot))
+    assert rc == 0
+    first = bytes(d_out.download(tot.value))
+    rc = engine.lib.zamd_deflate_shard_dev(engine.handle, d_in.ptr + split, n - split, 32768, chunk, 6, 0, 8, 1, d_out.ptr, cap, None, C.byref(tot))
+    assert rc == 0
+    second = bytes(d_out.download(tot.value))
+    assert first + second == whole
+
+
+def test_checksums(engine):
+    for n in (0, 1, 15, 16, 17, 5551, 5552, 5553, 65521, (1 << 20) - 1, 1 << 20, (5 << 20) + 3):
+        d = O.corpus(n, 4, 3)
+        assert engine.adler32(d) == zlib.adler32(d)
+        assert engine.crc32(d) == zlib.crc32(d)
+        assert engine.adler32(d, 0x12345) == zlib.adler32(d, 0x12345)
+        assert engine.crc32(d, 0xdeadbeef) == zlib.crc32(d, 0xdeadbeef)
+    # checksum of checksums: per-chunk values combined equal the whole-buffer value (64 MiB)
+    import ctypes as C
+    import zlib_amd
+    n = 64 << 20
+    data = bytes(zlib_amd.corpus(n, 4, 8, piece_bytes=16 << 20, threads=8))
+    buf = engine.alloc(n); buf.upload(data)
+    nch = n >> 20
+    da, dc = engine.alloc(4 * nch), engine.alloc(4 * nch)
+    assert engine.lib.zamd_checksums_dev(engine.handle, buf.ptr, n, 1 << 20, da.ptr, dc.ptr) == 0
+    ad = memoryview(da.download()).cast("I"); cr = memoryview(dc.download()).cast("I")
+    a, c = 1, 0
+    for i in range(nch):
+        assert ad[i] == zlib.adler32(data[i << 20:(i + 1) << 20])
+        a = zlib_amd.adler32_combine(a, ad[i], 1 << 20); c = zlib_amd.crc32_combine(c, cr[i], 1 << 20)
+    assert a == zlib.adler32(data) and c == zlib.crc32(data)
+
+
+def test_errors_are_loud(engine):
+    import ctypes as C
+    import zlib_amd
+    d = engine.alloc(1 << 16); o = engine.alloc(1 << 17)
+    tot = C.c_uint64(0)
+    lib = engine.lib
+    assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 0, 0, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
+    assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1000, 6, 0, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
+    assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 6, 7, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
+    d.upload(bytes(os.urandom(1 << 16)))
+    assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 6, 0, 8, 1, o.ptr, 1024, None, C.byref(tot)) == zlib_amd.Z_BUF_ERROR

@@ -45,6 +45,8 @@ def load_library() -> C.CDLL:
     lib.zamd_deflate_bound.restype = u64
     lib.zamd_deflate_dev.argtypes = [vp, vp, u64, u32, i32, i32, i32, i32, vp, u64, vp, C.POINTER(u64)]
     lib.zamd_deflate_dev.restype = i32
+    lib.zamd_deflate_shard_dev.argtypes = [vp, vp, u64, u32, u32, i32, i32, i32, i32, vp, u64, vp, C.POINTER(u64)]
+    lib.zamd_deflate_shard_dev.restype = i32
     lib.zamd_checksums_dev.argtypes = [vp, vp, u64, u32, vp, vp]
     lib.zamd_checksums_dev.restype = i32
     lib.zamd_adler32_dev.argtypes = [vp, u32, vp, u64, C.POINTER(u32)]
@@ -173,6 +175,16 @@ class Engine:
         total = C.c_uint64(0)
         _chk(self.lib.zamd_deflate_dev(self.handle, d_in, n, chunk_size, level, strategy, mem_level, int(finish),
                                        d_out, out_cap, d_chunk_off or None, C.byref(total)), "zamd_deflate_dev")
+        return total.value
+
+    def deflate_shard_dev(self, d_in: int, n: int, head_dict_len: int, d_out: int, out_cap: int, *, level: int = 6,
+                          strategy: int = 0, mem_level: int = 8, chunk_size: int = 1 << 20, finish: bool = True,
+                          d_chunk_off: int = 0) -> int:
+        """One shard of a larger input: the head_dict_len bytes before d_in are its first chunk's dictionary."""
+        total = C.c_uint64(0)
+        _chk(self.lib.zamd_deflate_shard_dev(self.handle, d_in, n, head_dict_len, chunk_size, level, strategy, mem_level,
+                                             int(finish), d_out, out_cap, d_chunk_off or None, C.byref(total)),
+             "zamd_deflate_shard_dev")
         return total.value
 
     def timing_ms(self, which: int) -> Tuple[float, int]:

@@ -75,10 +75,12 @@ struct ZcChunkGeom {
  * position whose head candidate at distance exactly MAX_DIST is lost to a
  * window slide in tail mode (fill_window called with no input left,
  * deflate.c:1419-1451), or ZC_NO_CORNER. */
-ZC_HD ZcChunkGeom zc_geom(uint64_t n, uint32_t chunk_size, uint64_t c, int finish)
+ZC_HD ZcChunkGeom zc_geom(uint64_t n, uint32_t chunk_size, uint64_t c, int finish, uint32_t head = 0)
 {
+    /* `head` bytes (0 or 32768) in front of chunk 0 belong to the buffer and are
+     * chunk 0's dictionary: a shard that continues somebody else's stream */
     ZcChunkGeom g;
-    uint64_t start = c * (uint64_t)chunk_size;
+    uint64_t start = head + c * (uint64_t)chunk_size;
     uint64_t rem = n - start;
     g.len = (uint32_t)(rem < chunk_size ? rem : chunk_size);
     g.dict_len = (uint32_t)(start < ZC_WSIZE ? start : ZC_WSIZE);

@@ -36,7 +36,7 @@ enum { ZE_CHAIN_ORDER = 1, ZE_BLOCK_OVERFLOW = 2, ZE_OUT_OVERFLOW = 4, ZE_INFLAT
 
 struct ZkJob {
     const uint8_t *in; uint64_t n;
-    uint64_t chunk0; uint32_t nchunks; int finish;
+    uint64_t chunk0; uint32_t nchunks; int finish; uint32_t head;
     ZcParams P;
     uint16_t *pdist; uint64_t pdist_base, pdist_len;
     uint2 *rec; uint64_t rec_base;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64) void k_chain(ZkJob J)
     __shared__ uint32_t head[32768];
     const uint32_t lane = threadIdx.x;
     const uint64_t c = J.chunk0 + blockIdx.x;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head);
     const uint32_t E = g.dict_len + g.len;
     /* positions with three bytes available in the whole input */
     uint64_t avail = J.n - g.dstart;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     __shared__ uint32_t s_next;
     const uint32_t tid = threadIdx.x;
     const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     if ((uint64_t)tile * ZK_TILE >= g.len) return;
     const uint32_t E = g.dict_len + g.len;
     const uint32_t t0 = g.dict_len + tile * ZK_TILE;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(64) void k_parse(ZkJob J)
 {
     uint32_t lc = blockIdx.x * 64 + threadIdx.x;
     if (lc >= J.nchunks) return;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     GRec rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
     GSym sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size;
     GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
     const uint32_t tid = threadIdx.x;
     const uint32_t lc = blockIdx.y, j = blockIdx.x;
     if (j >= J.nblk[lc]) return;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     ZcBlock *bp = J.blk + (uint64_t)lc * J.P.max_blocks + j;
     ZcBlock b = *bp;
     const uint8_t *src = J.in + g.dstart;
@@ -252,7 +252,7 @@ __global__ void k_layout(ZkJob J)
 {
     uint32_t lc = blockIdx.x * blockDim.x + threadIdx.x;
     if (lc >= J.nchunks) return;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     ZcBlock *base = J.blk + (uint64_t)lc * J.P.max_blocks;
     uint64_t sync = 0;
     /* a non-final chunk that is the last of a call without finish still ends on a sync marker */
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(ZK_EMIT_THREADS) void k_emit(ZkJob J)
     if (*J.err) return;
     const uint32_t nb = J.nblk[lc];
     if (j > nb) return;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     const uint64_t cbit = J.chunk_off[J.chunk0 + lc] * 8ull;
     uint32_t *out32 = J.out32;
     if (j == nb) {                                /* Z_SYNC_FLUSH marker: 000, pad, 00 00 FF FF */
@@ -623,11 +623,12 @@ static void tm_begin(zamd_engine *e, hipStream_t s, int which, int *slot)
 }
 static void tm_end(zamd_engine *e, hipStream_t s, int slot) { if (slot >= 0) hipEventRecord(e->tm[slot].b, s); }
 
-extern "C" int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chunk_size,
-                                int level, int strategy, int mem_level, int finish,
-                                void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out)
+extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t head_dict_len, uint32_t chunk_size,
+                                      int level, int strategy, int mem_level, int finish,
+                                      void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out)
 {
     if (!e || !d_out || (!d_in && n)) return ZAMD_STREAM_ERROR;
+    if (head_dict_len != 0 && head_dict_len != ZC_WSIZE) return ZAMD_STREAM_ERROR;
     if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
     ZcParams P;
     int rc = fill_params(P, level, strategy, mem_level, chunk_size);
@@ -668,12 +669,12 @@ extern "C" int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, ui
         hipStream_t s = e->st[si];
         ZeWorkspace &w = e->ws[si];
         ZkJob J; memset(&J, 0, sizeof J);
-        J.in = (const uint8_t *)d_in; J.n = n; J.chunk0 = (uint64_t)bi * batch;
+        J.in = (const uint8_t *)d_in - head_dict_len; J.n = n + head_dict_len; J.head = head_dict_len; J.chunk0 = (uint64_t)bi * batch;
         J.nchunks = (uint32_t)((total_chunks - J.chunk0) < batch ? (total_chunks - J.chunk0) : batch);
         J.finish = finish; J.P = P;
-        ZcChunkGeom g0 = zc_geom(n, chunk_size, J.chunk0, finish);
+        ZcChunkGeom g0 = zc_geom(J.n, chunk_size, J.chunk0, finish, J.head);
         J.pdist = w.pdist; J.pdist_base = g0.dstart; J.pdist_len = w.pdist_len;
-        J.rec = w.rec; J.rec_base = J.chunk0 * chunk_size;
+        J.rec = w.rec; J.rec_base = head_dict_len + J.chunk0 * chunk_size;
         J.sym = w.sym; J.blk = w.blk; J.tab = w.tab; J.nblk = w.nblk; J.nsym = w.nsym;
         J.chunk_bytes = w.chunk_bytes; J.sync_bit = w.sync_bit;
         J.chunk_off = d_off; J.running_total = e->d_total;
@@ -724,6 +725,13 @@ extern "C" int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, ui
     return ZAMD_OK;
 }
 
+extern "C" int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chunk_size,
+                                int level, int strategy, int mem_level, int finish,
+                                void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out)
+{
+    return zamd_deflate_shard_dev(e, d_in, n, 0, chunk_size, level, strategy, mem_level, finish, d_out, out_cap, d_chunk_off, total_out);
+}
+
 extern "C" double zamd_last_timing_ms(zamd_engine *e, int which, int *launches)
 {
     if (!e || which < 0 || which > 7) return 0;
@@ -735,7 +743,7 @@ extern "C" int64_t zamd_debug_dump(zamd_engine *e, int what, uint32_t chunk, voi
 {
     if (!e || !e->have_last || chunk >= e->last_job.nchunks) return ZAMD_STREAM_ERROR;
     const ZkJob &J = e->last_job;
-    ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + chunk, J.finish);
+    ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + chunk, J.finish, J.head);
     uint64_t cnt = 0; const void *src = nullptr; size_t esz = 0;
     uint32_t nb = 0, ns = 0;
     hipMemcpy(&nb, J.nblk + chunk, 4, hipMemcpyDeviceToHost);
