@@ -16,6 +16,7 @@ extern "C" {
 #include <cstdlib>
 #include <vector>
 
+static int g_hops = 0;   /* 1: decomposed lazy parse (resolve / hop / expand) instead of the serial replay */
 struct HostWin {
     const uint8_t *b; uint64_t n;    /* b = a-coordinate 0, n = bytes readable */
     uint32_t load4(uint32_t a) const { uint32_t v = 0; for (int k = 0; k < 4; k++) if ((uint64_t)a + k < n) v |= (uint32_t)b[a + k] << (8 * k); return v; }
@@ -75,7 +76,52 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
         uint32_t nsym = 0, nb;
         if (P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, P, blkst);
         else if (P.parser == ZC_PARSE_RLE) nb = zc_parse_rle(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
-        else nb = zc_parse_slow(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
+        else if (!g_hops) nb = zc_parse_slow(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
+        else {
+            /* k_resolve: hop word per position, literal skips to the next match inside a 1024-position tile */
+            std::vector<uint32_t> hop(g.len + 1, 0);
+            for (uint32_t i = 0; i < g.len; i++) hop[i] = zc_resolve_pos(rec, g.dict_len + i, E, P);
+            for (uint32_t t = 0; t < g.len; t += 1024) {
+                uint32_t te = t + 1024 < g.len ? t + 1024 : g.len, next = te;
+                for (uint32_t i = te; i-- > t;) { if (hop[i] & ZC_HOP_MATCH) next = i; else hop[i] = next - i; }
+            }
+            /* k_hop: the serial walk */
+            std::vector<uint32_t> arr;
+            for (uint32_t i = 0; i < g.len;) { uint32_t h = hop[i]; if (h & ZC_HOP_MATCH) { arr.push_back(i); i += zc_hop_k(h) + zc_hop_len(h); } else i += h; }
+            /* k_expand: symbols, then blocks from the symbol positions */
+            std::vector<uint32_t> spos;       /* start position of every symbol (a-coordinates) */
+            uint32_t endp = g.dict_len;
+            for (size_t hI = 0; hI <= arr.size(); hI++) {
+                uint32_t a = hI < arr.size() ? g.dict_len + arr[hI] : E;
+                uint32_t h = hI < arr.size() ? hop[arr[hI]] : 0;
+                uint32_t lits = (a - endp) + (hI < arr.size() ? zc_hop_k(h) : 0);
+                for (uint32_t o = 0; o < lits; o++) { sym[nsym] = endp + o; spos.push_back(endp + o); nsym++; }
+                if (hI < arr.size()) {
+                    uint32_t m = a + zc_hop_k(h);
+                    sym[nsym] = zc_sym_match(zc_hop_len(h), zc_hop_dist(h)); spos.push_back(m); nsym++;
+                    endp = m + zc_hop_len(h);
+                }
+            }
+            const uint32_t lim = P.lit_bufsize - 1;
+            bool tail_lit = nsym && !(sym[nsym - 1] & ZC_SYM_MATCH) && sym[nsym - 1] == E - 1;
+            nb = zc_block_count(nsym, lim, g.final, tail_lit);
+            uint32_t in_start = g.dict_len;
+            for (uint32_t b = 0; b < nb; b++) {
+                ZcBlock B; memset(&B, 0, sizeof B);
+                B.sym_start = b * lim; B.sym_count = (b + 1 < nb) ? lim : nsym - b * lim;
+                bool lastb = b + 1 == nb;
+                uint32_t in_end, p_top;
+                if (lastb) { in_end = E; p_top = E; }
+                else {
+                    uint32_t sI = (b + 1) * lim - 1, w = sym[sI];
+                    in_end = (w & ZC_SYM_MATCH) ? spos[sI] + ((w >> 16) & 0xff) + 3 : spos[sI] + 1;
+                    p_top = spos[sI] + 1;
+                }
+                B.in_start = in_start; B.in_len = in_end - in_start;
+                B.flags = ((lastb && g.final) ? ZC_BF_LAST : 0u) | (in_start >= zc_window_base(p_top, E, ZC_MIN_LOOK) ? ZC_BF_CANSTORE : 0u);
+                blkst(b, B); in_start = in_end;
+            }
+        }
         /* k_plan */
         std::vector<ZcBlockTab> tabs(nb);
         for (uint32_t j = 0; j < nb; j++) {
@@ -144,6 +190,7 @@ int main(int argc, char **argv)
 {
     long iters = argc > 1 ? atol(argv[1]) : 60;
     if (argc > 2) rs = strtoull(argv[2], 0, 10) | 1;
+    if (argc > 3) g_hops = atoi(argv[3]);
     /* closed-form code tables vs the reference's tables (via the oracle's trace is indirect; check self-consistency) */
     for (uint32_t lc = 0; lc < 256; lc++) { uint32_t c = zc_len_code(lc); if (lc < zc_len_base(c) || lc - zc_len_base(c) >= (1u << zc_len_extra(c)) + (c == 28)) { printf("len code table broken at %u\n", lc); return 1; } }
     for (uint32_t d = 0; d < 32768; d++) { uint32_t c = zc_dist_code(d); if (c >= 30 || d < zc_dist_base(c) || d - zc_dist_base(c) >= (1u << zc_dist_extra(c))) { printf("dist code table broken at %u\n", d); return 1; } }

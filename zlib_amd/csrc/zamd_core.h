@@ -208,53 +208,100 @@ ZC_HD uint32_t zc_sym_bits(uint32_t sym, uint32_t lit_byte, const LTab &ltab, co
  * pd(a) the distance from a to the previous string with the same hash (0 =
  * none within 32767).  Result words: len | dist << 16, len = 0 for "no match".
  */
+struct ZcMatchState {
+    uint32_t p, cur, k, best, bdist, qrec, cap, nice, scan3, qset;
+};
+
+/* Sets up the walk for position p.  Returns false when p has no usable head
+ * candidate (its record is then 0, 0). */
+template <class Win, class Pd>
+ZC_HD bool zc_match_init(const Win &win, const Pd &pd, uint32_t p, uint32_t E, uint32_t corner,
+                         uint32_t nice_match, ZcMatchState &s)
+{
+    uint32_t look = E - p;
+    if (look < ZC_MIN_MATCH) return false;                 /* no INSERT_STRING, deflate.c:1756 */
+    uint32_t d0 = pd(p);
+    if (d0 == 0 || d0 > ZC_MAX_DIST) return false;         /* hash_head == NIL or too far, :1765-1766 */
+    if (d0 >= p) return false;                             /* window index 0 is NIL */
+    if (p == corner && d0 == ZC_MAX_DIST) return false;    /* slid onto index 0 in tail mode */
+    s.p = p; s.cur = p - d0; s.k = 0; s.best = ZC_MIN_MATCH - 1; s.bdist = 0; s.qrec = 0; s.qset = 0;
+    s.cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
+    s.nice = nice_match < look ? nice_match : look;        /* :1191 */
+    s.scan3 = win.load4(p) & 0x00ffffffu;
+    return true;
+}
+
+/* One chain step in three pieces, so that a kernel can overlap the loads of
+ * several walks and batch the rare long comparisons:
+ *   zc_match_peek     loads the three bytes that decide whether s.cur can beat
+ *                     s.best, and the link to the next chain member
+ *   zc_match_extend   full comparison of a candidate that passed the peek;
+ *                     returns true when it reached nice length (walk over)
+ *   zc_match_advance  chain budget, quarter-budget snapshot, link and distance
+ *                     limit; returns true when the walk is over */
+template <class Win, class Pd>
+ZC_HD void zc_match_peek(const Win &win, const Pd &pd, const ZcMatchState &s, uint32_t *c3, uint32_t *d)
+{
+    *c3 = win.load4(s.cur + s.best - 2u) & 0x00ffffffu;
+    *d = pd(s.cur);
+}
+
+template <class Win>
+ZC_HD bool zc_match_extend(const Win &win, ZcMatchState &s)
+{
+    uint32_t len = 0;
+    while (len < s.cap) {
+        uint32_t x = win.load4(s.cur + len) ^ win.load4(s.p + len);
+        if (x) { len += zc_ctz32(x) >> 3; break; }
+        len += 4;
+    }
+    if (len > s.cap) len = s.cap;
+    if (len > s.best) {
+        s.best = len; s.bdist = s.p - s.cur;
+        if (len >= s.nice) { s.k++; return true; }         /* :1276 */
+        s.scan3 = win.load4(s.p + len - 2u) & 0x00ffffffu;
+    }
+    return false;
+}
+
+ZC_HD bool zc_match_advance(ZcMatchState &s, uint32_t d, uint32_t max_chain)
+{
+    s.k++;
+    if (s.k == (max_chain >> 2)) { s.qrec = s.best >= ZC_MIN_MATCH ? (s.best | (s.bdist << 16)) : 0; s.qset = 1; }
+    if (s.k >= max_chain) return true;
+    if (d == 0 || d >= s.cur) return true;                 /* end of chain, or window index <= 0 */
+    s.cur -= d;
+    return s.p - s.cur >= ZC_MAX_DIST;                     /* cur <= limit, :1158, 1284 */
+}
+
+/* Examines the candidate s.cur and moves to the next chain member.  Returns
+ * true when the walk is over. */
+template <class Win, class Pd>
+ZC_HD bool zc_match_step(const Win &win, const Pd &pd, uint32_t max_chain, ZcMatchState &s)
+{
+    uint32_t c3, d;
+    zc_match_peek(win, pd, s, &c3, &d);
+    if (c3 == s.scan3 && zc_match_extend(win, s)) return true;
+    return zc_match_advance(s, d, max_chain);
+}
+
+ZC_HD void zc_match_result(const ZcMatchState &s, uint32_t max_chain, uint32_t *rec_full, uint32_t *rec_quarter)
+{
+    uint32_t full = s.best >= ZC_MIN_MATCH ? (s.best | (s.bdist << 16)) : 0;
+    uint32_t qbudget = max_chain >> 2;
+    *rec_full = full;
+    *rec_quarter = qbudget == 0 ? 0u : ((s.qset && s.k > qbudget) ? s.qrec : full);
+}
+
 template <class Win, class Pd>
 ZC_HD void zc_match_pos(const Win &win, const Pd &pd, uint32_t p, uint32_t E, uint32_t corner,
                         uint32_t nice_match, uint32_t max_chain, uint32_t *rec_full, uint32_t *rec_quarter)
 {
+    ZcMatchState s;
     *rec_full = 0; *rec_quarter = 0;
-    uint32_t look = E - p;
-    if (look < ZC_MIN_MATCH) return;                       /* no INSERT_STRING, deflate.c:1756 */
-    uint32_t d0 = pd(p);
-    if (d0 == 0 || d0 > ZC_MAX_DIST) return;               /* hash_head == NIL or too far, :1765-1766 */
-    uint32_t cur = p - d0;
-    if (cur == 0) return;                                  /* window index 0 is NIL */
-    if (p == corner && d0 == ZC_MAX_DIST) return;          /* slid onto index 0 in tail mode */
-    uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
-    uint32_t nice = nice_match < look ? nice_match : look; /* :1191 */
-    uint32_t qbudget = max_chain >> 2;
-    uint32_t best = ZC_MIN_MATCH - 1, bdist = 0, k = 0, qrec = 0;
-    bool qset = false;
-    for (;;) {
-        /* candidate `cur` can only beat `best` if bytes best-2..best agree (and best < cap) */
-        uint32_t off = best - 2u;                          /* >= 0 */
-        uint32_t mask = 0x00ffffffu;
-        if (((win.load4(cur + off) ^ win.load4(p + off)) & mask) == 0) {
-            uint32_t len = 0;
-            while (len < cap) {
-                uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
-                if (x) { len += zc_ctz32(x) >> 3; break; }
-                len += 4;
-            }
-            if (len > cap) len = cap;
-            if (len > best) {
-                best = len; bdist = p - cur;
-                if (len >= nice) { k++; break; }
-            }
-        }
-        k++;
-        if (k == qbudget) { qrec = best >= ZC_MIN_MATCH ? (best | (bdist << 16)) : 0; qset = true; }
-        if (k >= max_chain) break;
-        uint32_t d = pd(cur);
-        if (d == 0) break;
-        if (d >= cur) break;                               /* would reach a <= 0: NIL */
-        cur -= d;
-        if (p - cur >= ZC_MAX_DIST) break;                 /* cur <= limit, :1158, 1284 */
-    }
-    uint32_t full = best >= ZC_MIN_MATCH ? (best | (bdist << 16)) : 0;
-    *rec_full = full;
-    *rec_quarter = (qset && k > qbudget) ? qrec : full;
-    if (qbudget == 0) *rec_quarter = 0;
+    if (!zc_match_init(win, pd, p, E, corner, nice_match, s)) return;
+    while (!zc_match_step(win, pd, max_chain, s)) {}
+    zc_match_result(s, max_chain, rec_full, rec_quarter);
 }
 
 /* Z_RLE (deflate.c:1884-1898): run of bytes equal to the previous byte. */
@@ -349,6 +396,82 @@ ZC_HD uint32_t zc_parse_slow(uint32_t dict_len, uint32_t len, uint32_t final_, c
     else if (out.nsym != out.blk_sym0) out.flush(p, 0, w);
     *nsym_out = out.nsym;
     return out.nblk;
+}
+
+/* ------------------------------------------------------------------ lazy parse, decomposed
+ * The replay above is serial in the position.  Most of it is not: whenever
+ * deflate_slow reaches a position with nothing pending (after a match was
+ * emitted, or while it is only carrying a literal), what it does next depends on
+ * the match records alone.  zc_resolve_pos() computes that for every position in
+ * parallel: the hop word says "k lazy literals, then the match (L, D)"; the only
+ * serial part left is following the hops (zc_hop_next), and the symbol stream and
+ * block table are expanded from the hop list in parallel.
+ *
+ * hop word: bit 31 set = match hop: D in bits 0-14, L-3 in bits 15-22, k in bits
+ * 23-30; bit 31 clear = no match starts here: the value is how many positions to
+ * step over as literals (filled in by the caller, 0 from zc_resolve_pos). */
+#define ZC_HOP_MATCH 0x80000000u
+ZC_HD uint32_t zc_hop_pack(uint32_t k, uint32_t L, uint32_t D) { return ZC_HOP_MATCH | (k << 23) | ((L - 3u) << 15) | D; }
+ZC_HD uint32_t zc_hop_k(uint32_t h) { return (h >> 23) & 0xffu; }
+ZC_HD uint32_t zc_hop_len(uint32_t h) { return ((h >> 15) & 0xffu) + 3u; }
+ZC_HD uint32_t zc_hop_dist(uint32_t h) { return h & 0x7fffu; }
+
+/* longest_match's result as the caller sees it (deflate.c:1771-1785): the record
+ * chosen by prev_length, accepted only if longer, then the TOO_FAR / Z_FILTERED rule */
+ZC_HD bool zc_accept(uint32_t rf, uint32_t rq, uint32_t plen, const ZcParams &P, uint32_t *L, uint32_t *D)
+{
+    uint32_t v = plen >= P.good ? rq : rf;
+    uint32_t l = v & 0xffffu, d = v >> 16;
+    if (l <= plen) return false;
+    if (l <= 5 && (P.strategy == ZC_STRAT_FILTERED || (l == ZC_MIN_MATCH && d > ZC_TOO_FAR))) return false;
+    *L = l; *D = d;
+    return true;
+}
+
+template <class Rec>
+ZC_HD uint32_t zc_resolve_pos(Rec rec, uint32_t p, uint32_t E, const ZcParams &P)
+{
+    uint32_t rf, rq, L, D;
+    if (E - p < ZC_MIN_MATCH) return 0;
+    rec(p, &rf, &rq);
+    if (!zc_accept(rf, rq, ZC_MIN_MATCH - 1, P, &L, &D)) return 0;
+    uint32_t k = 0;
+    for (;;) {                                             /* deflate.c:1762-1837 at position p + k + 1 */
+        uint32_t q = p + k + 1, L2, D2;
+        if (L >= P.lazy || E - q < ZC_MIN_MATCH) break;
+        rec(q, &rf, &rq);
+        if (!zc_accept(rf, rq, L, P, &L2, &D2)) break;
+        L = L2; D = D2; k++;
+    }
+    return zc_hop_pack(k, L, D);
+}
+
+/* Window base (a-coordinate of window index 0) in force at the iteration that
+ * starts at p_top, for a chunk that ends at E: fill_window slides by 32 KiB at
+ * the first iteration top that is both short of lookahead (< look_thr bytes
+ * left in the window) and at window index >= 65274 (deflate.c:1419, 1744). */
+ZC_HD uint32_t zc_window_base(uint32_t p_top, uint32_t E, uint32_t look_thr)
+{
+    uint32_t B = 0;
+    for (;;) {
+        uint64_t cap = (uint64_t)B + 2u * ZC_WSIZE;
+        uint32_t wend = E < cap ? E : (uint32_t)cap;
+        uint32_t t1 = wend >= look_thr - 1 ? wend - (look_thr - 1) : 0, t2 = B + ZC_WSIZE + ZC_MAX_DIST;
+        uint32_t thr = t1 > t2 ? t1 : t2;
+        if (p_top < thr) return B;
+        B += ZC_WSIZE;
+    }
+}
+
+/* Number of blocks a chunk of nsym symbols is cut into (lit_bufsize rule,
+ * trees.c:1050) and block b's symbol range.  tail_literal: the last symbol is
+ * the literal deflate_slow tallies after its loop (deflate.c:1840-1844), whose
+ * "buffer full" result is ignored. */
+ZC_HD uint32_t zc_block_count(uint32_t nsym, uint32_t lim, uint32_t final_, bool tail_literal)
+{
+    uint32_t full = nsym / lim, rem = nsym % lim;
+    if (rem == 0 && nsym != 0 && tail_literal) return full;
+    return full + ((final_ || rem) ? 1u : 0u);
 }
 
 /* deflate_rle() (deflate.c:1861-1928) over precomputed run lengths. */

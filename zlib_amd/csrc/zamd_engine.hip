@@ -41,6 +41,7 @@ struct ZkJob {
     uint16_t *pdist; uint64_t pdist_base, pdist_len;
     uint2 *rec; uint64_t rec_base;
     uint32_t *sym;
+    uint32_t *hop; uint32_t *arr; uint32_t *nhop;
     ZcBlock *blk; ZcBlockTab *tab;
     uint32_t *nblk; uint32_t *nsym;
     uint64_t *chunk_bytes; uint64_t *sync_bit;
@@ -69,21 +70,41 @@ __global__ __launch_bounds__(64) void k_chain(ZkJob J)
     for (uint32_t pass = 0; pass < passes; pass++) {
         for (uint32_t i = lane; i < 32768; i += 64) head[i] = 0;
         __syncthreads();
-        for (uint32_t a0 = 0; a0 < Ex; a0 += 64) {
-            uint32_t a = a0 + lane;
-            bool valid = a < Ex;
-            uint32_t h = 0;
-            if (valid) h = zc_hash3(src[a], src[a + 1], src[a + 2], J.P.hash_shift, J.P.hash_mask);
-            bool mine = valid && (h >> 15) == pass;
-            uint32_t old = 0;
-            /* LDS atomic max: lanes hold increasing positions, so the value returned
-             * to a lane is the newest earlier string with the same hash */
-            if (mine) old = atomicMax(&head[h & 32767u], a + 1);
-            if (mine) {
-                if (old > a) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
-                uint32_t d = old ? a + 1 - old : 0;
-                if (d > 32767u) d = 0;
-                if (a >= out_from) pd[a] = (uint16_t)d;
+        /* four 64-position steps per iteration: all loads first, then the four LDS
+         * atomics back to back (one wave issues LDS operations in order), then the stores */
+        for (uint32_t a0 = 0; a0 < Ex; a0 += 256) {
+            uint32_t h[4]; bool mine[4]; uint32_t old[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t a = a0 + 64u * u + lane;
+                bool valid = a < Ex;
+                uint32_t b3 = 0;
+                if (valid) {
+                    uint32_t al = a & ~3u;
+                    if (g.dstart + al + 8 <= J.n) {
+                        uint32_t w0 = *(const uint32_t *)(src + al), w1 = *(const uint32_t *)(src + al + 4);
+                        b3 = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+                    } else b3 = (uint32_t)src[a] | ((uint32_t)src[a + 1] << 8) | ((uint32_t)src[a + 2] << 16);
+                }
+                h[u] = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
+                mine[u] = valid && (h[u] >> 15) == pass;
+            }
+            /* LDS atomic max: lanes (and successive steps) hold increasing positions, so the
+             * value returned to a lane is the newest earlier string with the same hash */
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                old[u] = 0;
+                if (mine[u]) old[u] = atomicMax(&head[h[u] & 32767u], a0 + 64u * u + lane + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t a = a0 + 64u * u + lane;
+                if (mine[u]) {
+                    if (old[u] > a) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
+                    uint32_t d = old[u] ? a + 1 - old[u] : 0;
+                    if (d > 32767u) d = 0;
+                    if (a >= out_from) pd[a] = (uint16_t)d;
+                }
             }
         }
         __syncthreads();
@@ -93,6 +114,10 @@ __global__ __launch_bounds__(64) void k_chain(ZkJob J)
 }
 
 /* ------------------------------------------------------------------ k_match */
+#define ZK_PD_OFF   ZK_WIN_BYTES                 /* byte offset of the link image inside the LDS block */
+#define ZK_LDS_BYTES (ZK_WIN_BYTES + 2u * (ZK_HALO + ZK_TILE))
+#define ZK_PD_NONE  0xffffu                      /* "no earlier string" in the LDS link image */
+
 struct LdsWin {
     const uint32_t *w; uint32_t a0;
     __device__ uint32_t load4(uint32_t a) const
@@ -103,14 +128,15 @@ struct LdsWin {
 };
 struct LdsPd {
     const uint16_t *pd; uint32_t a0;
-    __device__ uint32_t operator()(uint32_t a) const { return pd[a - a0]; }
+    __device__ uint32_t operator()(uint32_t a) const { uint32_t v = pd[a - a0]; return v == ZK_PD_NONE ? 0u : v; }
 };
 
 __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t tiles_per_chunk, int rle)
 {
-    __shared__ uint32_t s_win[ZK_WIN_BYTES / 4];
-    __shared__ uint16_t s_pd[ZK_HALO + ZK_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t s_lds[ZK_LDS_BYTES / 4];
     __shared__ uint32_t s_next;
+    uint32_t *s_win = s_lds;
+    uint16_t *s_pd = (uint16_t *)(s_lds + ZK_PD_OFF / 4);
     const uint32_t tid = threadIdx.x;
     const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
@@ -136,6 +162,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         ((uint4 *)s_win)[v] = q;
     }
     if (!rle) {
+        /* chain links; "none" (0) is stored as 0xffff so that adding it to a distance always exceeds MAX_DIST */
         for (uint32_t v = tid; v < (ZK_HALO + ZK_TILE) / 8; v += ZK_MATCH_THREADS) {
             int64_t a = a0 + 8 * (int64_t)v;
             uint4 q = make_uint4(0, 0, 0, 0);
@@ -143,7 +170,13 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 uint64_t idx = g.dstart + (uint64_t)a - J.pdist_base;
                 if (idx + 8 <= J.pdist_len) q = *(const uint4 *)(J.pdist + idx);
             }
-            ((uint4 *)s_pd)[v] = q;
+            uint32_t t[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((t[k] & 0xffffu) == 0) t[k] |= 0xffffu;
+                if ((t[k] >> 16) == 0) t[k] |= 0xffff0000u;
+            }
+            ((uint4 *)s_pd)[v] = make_uint4(t[0], t[1], t[2], t[3]);
         }
     }
     if (tid == 0) s_next = 0;
@@ -152,47 +185,344 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     LdsPd pd; pd.pd = s_pd; pd.a0 = (uint32_t)a0;
     uint2 *rec = J.rec + (g.dstart + t0 - J.rec_base);
     const uint32_t lane = tid & 63u;
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&s_next, 64u);
-        base = __shfl(base, 0);
-        if (base >= tlen) break;
-        uint32_t i = base + lane;
-        if (i < tlen) {
-            uint32_t rf, rq;
-            if (rle) { rf = zc_rle_pos(win, t0 + i, E); rq = rf; }
-            else zc_match_pos(win, pd, t0 + i, E, g.corner, J.P.nice, J.P.chain, &rf, &rq);
-            rec[i] = make_uint2(rf, rq);
+    if (rle) {
+        for (;;) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, 64u);
+            base = __shfl(base, 0);
+            if (base >= tlen) break;
+            uint32_t i = base + lane;
+            if (i < tlen) { uint32_t r = zc_rle_pos(win, t0 + i, E); rec[i] = make_uint2(r, r); }
         }
+        return;
+    }
+    /* Persistent lanes.  A lane walks the chain of one position; a lane whose walk
+     * is over draws the next unclaimed position of the tile once enough lanes of
+     * the wavefront are idle, so chains of very different length do not leave the
+     * wavefront waiting on its slowest lane.  The per-candidate step makes the same
+     * decisions as zc_match_peek / zc_match_advance in zamd_core.h but is written
+     * as straight-line integer arithmetic on sign masks, because the scalar unit a
+     * CU's four SIMDs share is what nested predicates would saturate.  Candidates
+     * that pass the 3-byte peek are parked and compared in full, together, at the
+     * next service point. */
+    const uint32_t nice_match = J.P.nice, max_chain = J.P.chain, qb = max_chain >> 2;
+    const uint32_t QNONE = 0xffffffffu;
+    const uint32_t la0 = (uint32_t)a0;
+    uint32_t p = t0, cur = t0, best = 2, bdist = 0, qrec = QNONE, scan3 = 0, cap = 0, nice = 0;
+    int32_t kk = 0;                           /* candidates examined minus max_chain: negative while budget remains */
+    int32_t walking = 0, parked = 0;          /* sign masks: -1 / 0 */
+    bool exhausted = false;
+    for (;;) {
+        /* ---- full comparisons of parked candidates (zc_match_extend, then zc_match_advance) */
+        if (parked < 0) {
+            uint32_t len = 0;
+            while (len < cap) {
+                uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
+                if (x) { len += zc_ctz32(x) >> 3; break; }
+                len += 4;
+            }
+            if (len > cap) len = cap;
+            bool fin = false;
+            /* the step that parked this walk already counted the candidate */
+            if (len > best) {
+                best = len; bdist = p - cur;
+                if (len >= nice) fin = true;
+                else scan3 = win.load4(p + len - 2u) & 0x00ffffffu;
+            }
+            if (!fin) {
+                uint32_t d = pd(cur);
+                if ((uint32_t)(kk + (int32_t)max_chain) == qb) qrec = best >= 3u ? (best | (bdist << 16)) : 0u;
+                if (kk >= 0 || d == 0 || d >= cur) fin = true;
+                else { cur -= d; fin = p - cur >= ZC_MAX_DIST; }
+            }
+            parked = 0; walking = -1;
+            if (fin) {
+                uint32_t k = (uint32_t)(kk + (int32_t)max_chain);
+                uint32_t full = best >= 3u ? (best | (bdist << 16)) : 0u;
+                uint32_t rq = qb == 0 ? 0u : ((qrec != QNONE && k > qb) ? qrec : full);
+                rec[p - t0] = make_uint2(full, rq);
+                walking = 0;
+            }
+        }
+        /* ---- refill idle lanes */
+        unsigned long long idle = __ballot(walking == 0);
+        if (idle != 0ull && !exhausted) {
+            uint32_t cnt = (uint32_t)__popcll(idle), base = 0;
+            if (lane == 0) base = atomicAdd(&s_next, cnt);
+            base = __shfl(base, 0);
+            if (base + cnt >= tlen) exhausted = true;
+            if (walking == 0) {
+                uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (idx < tlen) {
+                    ZcMatchState st;
+                    if (zc_match_init(win, pd, t0 + idx, E, g.corner, nice_match, st)) {
+                        p = st.p; cur = st.cur; kk = -(int32_t)max_chain; best = 2; bdist = 0; qrec = QNONE;
+                        scan3 = st.scan3; cap = st.cap; nice = st.nice;
+                        walking = -1;
+                    } else rec[idx] = make_uint2(0u, 0u);
+                }
+            }
+        }
+        if (__ballot(walking < 0) == 0ull) { if (exhausted) break; continue; }
+        /* ---- candidate steps until a quarter of the lanes need service */
+        const uint32_t full_now = best >= 3u ? (best | (bdist << 16)) : 0u;   /* best is fixed while walking */
+        const uint32_t boff = best - 2u;
+        const uint32_t pout = p - t0;
+        const int32_t lim = (int32_t)(p < ZC_MAX_DIST ? p : ZC_MAX_DIST);      /* stop once the distance reaches this */
+        const int32_t kq = (int32_t)qb - (int32_t)max_chain;
+        uint32_t curi = cur - la0;            /* LDS-relative index of the candidate */
+        int32_t dist = (int32_t)(p - cur);
+        int32_t wm = walking;
+#pragma unroll 1
+        for (int it = 0; it < 64; it++) {
+            const uint32_t ac = curi + boff;
+            const uint32_t wi = ac >> 2;
+            const uint32_t w0 = s_win[wi], w1 = s_win[wi + 1];
+            const int32_t d = (int32_t)s_pd[curi];
+            const uint32_t x = (__builtin_amdgcn_alignbyte(w1, w0, ac & 3u) & 0x00ffffffu) ^ scan3;
+            const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
+            const int32_t hit = (int32_t)(x - 1u) & wm;      /* negative iff walking and matched */
+            kk -= wm;                                         /* count the candidate */
+            qrec = (kk == kq && wm < 0) ? full_now : qrec;   /* a parked walk redoes this after its comparison */
+            const int32_t dn = dist + d;
+            const int32_t go = (dn - lim) & kk & nohit & wm; /* negative iff the walk continues */
+            const int32_t fin = nohit & wm & ~go;             /* negative iff the walk ends here */
+            if (fin < 0) {
+                uint32_t k = (uint32_t)(kk - kq) + qb;
+                uint32_t rq = qb == 0 ? 0u : ((qrec != QNONE && k > qb) ? qrec : full_now);
+                rec[pout] = make_uint2(full_now, rq);
+            }
+            dist = go < 0 ? dn : dist;
+            curi = go < 0 ? curi - (uint32_t)d : curi;
+            parked |= hit;
+            wm = go >> 31;
+            if (__popcll(__ballot(wm == 0)) >= 16) break;
+        }
+        cur = curi + la0;
+        walking = wm | (parked >> 31);        /* parked walks are still owned by the lane */
+        parked >>= 31;
+        if (parked < 0) walking = 0 | walking;
     }
 }
 
-/* ------------------------------------------------------------------ k_parse */
-struct GRec {
-    const uint2 *r;               /* indexed by a - dict_len */
-    uint32_t dict_len;
-    __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q) const { uint2 v = r[p - dict_len]; *f = v.x; *q = v.y; }
+/* ------------------------------------------------------------------ k_parse
+ * One wavefront per chunk.  The lazy-evaluation state machine is serial, so all
+ * 64 lanes run it redundantly (every value is wave-uniform, branches are scalar)
+ * and use their width only to stream the match records through a small LDS tile
+ * with coalesced loads; lane 0 writes symbols and blocks. */
+#define ZK_PARSE_TILE 1024u
+struct TileRec {
+    const uint2 *g;               /* records of this chunk, index = a - dict_len */
+    uint2 *tile;                  /* LDS, ZK_PARSE_TILE entries */
+    uint32_t dict_len, len, base, lane;
+    __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q)
+    {
+        uint32_t i = p - dict_len;
+        if (i - base >= ZK_PARSE_TILE) {
+            base = i & ~(ZK_PARSE_TILE - 1u);
+            __syncthreads();
+            for (uint32_t k = lane * 2u; k < ZK_PARSE_TILE; k += 128u) {
+                uint32_t idx = base + k;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (idx + 2u <= len) v = *(const uint4 *)(g + idx);
+                else if (idx < len) { uint2 t = g[idx]; v.x = t.x; v.y = t.y; }
+                *(uint4 *)(tile + k) = v;
+            }
+            __syncthreads();
+        }
+        uint2 v = tile[i - base];
+        *f = v.x; *q = v.y;
+    }
 };
-struct GSym { uint32_t *s; __device__ void operator()(uint32_t i, uint32_t w) const { s[i] = w; } };
+struct GSym { uint32_t *s; uint32_t lane; __device__ void operator()(uint32_t i, uint32_t w) const { if (lane == 0) s[i] = w; } };
 struct GBlk {
-    ZcBlock *b; uint32_t cap; uint32_t *err;
-    __device__ void operator()(uint32_t i, const ZcBlock &v) const { if (i < cap) b[i] = v; else atomicOr(err, (uint32_t)ZE_BLOCK_OVERFLOW); }
+    ZcBlock *b; uint32_t cap; uint32_t *err; uint32_t lane;
+    __device__ void operator()(uint32_t i, const ZcBlock &v) const
+    {
+        if (lane != 0) return;
+        if (i < cap) b[i] = v; else atomicOr(err, (uint32_t)ZE_BLOCK_OVERFLOW);
+    }
 };
 
 __global__ __launch_bounds__(64) void k_parse(ZkJob J)
 {
-    uint32_t lc = blockIdx.x * 64 + threadIdx.x;
-    if (lc >= J.nchunks) return;
+    __shared__ uint2 s_tile[ZK_PARSE_TILE];
+    const uint32_t lc = blockIdx.x, lane = threadIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
-    GRec rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
-    GSym sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size;
-    GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err;
+    TileRec rec; rec.g = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.tile = s_tile;
+    rec.dict_len = g.dict_len; rec.len = g.len; rec.base = 0xffff0000u; rec.lane = lane;
+    GSym sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size; sym.lane = lane;
+    GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
     uint32_t nsym = 0, nb;
     if (J.P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, J.P, blk);
     else if (J.P.parser == ZC_PARSE_RLE) nb = zc_parse_rle(g.dict_len, g.len, g.final, J.P, rec, sym, blk, &nsym);
     else nb = zc_parse_slow(g.dict_len, g.len, g.final, J.P, rec, sym, blk, &nsym);
-    J.nblk[lc] = nb < J.P.max_blocks ? nb : J.P.max_blocks;
-    J.nsym[lc] = nsym;
+    if (lane == 0) {
+        J.nblk[lc] = nb < J.P.max_blocks ? nb : J.P.max_blocks;
+        J.nsym[lc] = nsym;
+    }
+}
+
+/* ------------------------------------------------------------------ k_resolve / k_hop / k_expand
+ * The lazy parser (deflate_slow) split into a parallel part, a short serial
+ * part and a parallel part; see zc_resolve_pos in zamd_core.h. */
+#define ZK_RESOLVE_TILE 1024u
+struct GRec2 {
+    const uint2 *r; uint32_t dict_len;
+    __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q) const { uint2 v = r[p - dict_len]; *f = v.x; *q = v.y; }
+};
+
+__global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t tiles_per_chunk)
+{
+    __shared__ unsigned long long s_mask[ZK_RESOLVE_TILE / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const uint32_t i0 = tile * ZK_RESOLVE_TILE;
+    if (i0 >= g.len) return;
+    const uint32_t tl = g.len - i0 < ZK_RESOLVE_TILE ? g.len - i0 : ZK_RESOLVE_TILE;
+    const uint32_t E = g.dict_len + g.len;
+    GRec2 rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
+    uint32_t h = 0;
+    if (tid < tl) h = zc_resolve_pos(rec, g.dict_len + i0 + tid, E, J.P);
+    unsigned long long m = __ballot((h & ZC_HOP_MATCH) != 0);
+    if (lane == 0) s_mask[wv] = m;
+    __syncthreads();
+    if (tid < tl && !(h & ZC_HOP_MATCH)) {
+        /* literal: distance to the next position of the tile where a match starts (or to the tile's end) */
+        unsigned long long mm = m & (~0ull << lane);
+        uint32_t next = tl;
+        if (mm) next = wv * 64u + (uint32_t)__ffsll((long long)mm) - 1u;
+        else for (uint32_t w = wv + 1; w < ZK_RESOLVE_TILE / 64; w++) {
+            unsigned long long x = s_mask[w];
+            if (x) { next = w * 64u + (uint32_t)__ffsll((long long)x) - 1u; break; }
+        }
+        if (next > tl) next = tl;
+        h = next - tid;
+    }
+    if (tid < tl) J.hop[(uint64_t)lc * J.P.chunk_size + i0 + tid] = h;
+}
+
+#define ZK_HOP_TILE 2048u
+__global__ __launch_bounds__(64) void k_hop(ZkJob J)
+{
+    __shared__ uint32_t s_tile[ZK_HOP_TILE];
+    const uint32_t lc = blockIdx.x, lane = threadIdx.x;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;
+    uint32_t *arr = J.arr + (uint64_t)lc * (J.P.chunk_size / 2);
+    uint32_t i = 0, H = 0, base = 0xffff0000u;
+    while (i < g.len) {
+        if (i - base >= ZK_HOP_TILE) {
+            base = i & ~(ZK_HOP_TILE - 1u);
+            __syncthreads();
+            for (uint32_t k = lane * 4u; k < ZK_HOP_TILE; k += 256u) {
+                uint32_t idx = base + k;
+                uint4 v = make_uint4(1, 1, 1, 1);
+                if (idx + 4u <= g.len) v = *(const uint4 *)(hop + idx);
+                else { if (idx < g.len) v.x = hop[idx]; if (idx + 1 < g.len) v.y = hop[idx + 1]; if (idx + 2 < g.len) v.z = hop[idx + 2]; }
+                *(uint4 *)(s_tile + k) = v;
+            }
+            __syncthreads();
+        }
+        uint32_t h = s_tile[i - base];
+        if (h & ZC_HOP_MATCH) {
+            if (lane == 0) arr[H] = i;
+            H++;
+            i += zc_hop_k(h) + zc_hop_len(h);
+        } else i += h;
+    }
+    if (lane == 0) J.nhop[lc] = H;
+}
+
+#define ZK_EXPAND_THREADS 256
+__global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
+{
+    __shared__ uint32_t s_off[ZK_EXPAND_THREADS + 1], s_lit0[ZK_EXPAND_THREADS], s_lits[ZK_EXPAND_THREADS];
+    __shared__ uint32_t s_word[ZK_EXPAND_THREADS], s_mpos[ZK_EXPAND_THREADS], s_end[ZK_EXPAND_THREADS];
+    __shared__ uint32_t s_wsum[ZK_EXPAND_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t lc = blockIdx.x;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const uint32_t E = g.dict_len + g.len, lim = J.P.lit_bufsize - 1;
+    const uint32_t H = J.nhop[lc];
+    const uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;
+    const uint32_t *arr = J.arr + (uint64_t)lc * (J.P.chunk_size / 2);
+    uint32_t *sym = J.sym + (uint64_t)lc * J.P.chunk_size;
+    ZcBlock *blk = J.blk + (uint64_t)lc * J.P.max_blocks;
+    uint32_t base_sym = 0, endp = g.dict_len, tail_lits = 0;
+    for (uint32_t t = 0; t <= H; t += ZK_EXPAND_THREADS) {
+        const uint32_t j = t + tid;
+        uint32_t a = E, k = 0, L = 0, D = 0, myend = E;
+        if (j < H) {
+            uint32_t ai = arr[j], h = hop[ai];
+            a = g.dict_len + ai; k = zc_hop_k(h); L = zc_hop_len(h); D = zc_hop_dist(h);
+            myend = a + k + L;
+        }
+        s_end[tid] = myend;
+        __syncthreads();
+        const uint32_t prev = tid ? s_end[tid - 1] : endp;
+        uint32_t lits = 0, cnt = 0;
+        if (j <= H) { lits = (a - prev) + k; cnt = lits + (j < H ? 1u : 0u); }
+        if (j == H) tail_lits = lits;
+        /* exclusive scan of the symbol counts */
+        uint32_t incl = cnt;
+        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+        for (uint32_t w = 0; w < ZK_EXPAND_THREADS / 64; w++) { uint32_t x = s_wsum[w]; if (w < wv) woff += x; total += x; }
+        s_off[tid] = woff + incl - cnt;
+        if (tid == 0) s_off[ZK_EXPAND_THREADS] = total;
+        s_lit0[tid] = prev; s_lits[tid] = lits;
+        s_word[tid] = j < H ? zc_sym_match(L, D) : 0u; s_mpos[tid] = a + k;
+        __syncthreads();
+        for (uint32_t x = tid; x < total; x += ZK_EXPAND_THREADS) {
+            uint32_t lo = 0, hi = ZK_EXPAND_THREADS;          /* last q with s_off[q] <= x */
+            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= x) lo = mid; else hi = mid; }
+            const uint32_t o = x - s_off[lo];
+            uint32_t word, pos, endpos;
+            if (o < s_lits[lo]) { pos = s_lit0[lo] + o; word = pos; endpos = pos + 1; }
+            else { word = s_word[lo]; pos = s_mpos[lo]; endpos = pos + ((word >> 16) & 0xffu) + 3u; }
+            const uint32_t sidx = base_sym + x;
+            sym[sidx] = word;
+            if ((sidx + 1) % lim == 0) {
+                uint32_t b = (sidx + 1) / lim - 1;
+                if (b < J.P.max_blocks) { blk[b].bits = endpos; blk[b].hdr_bits = pos + 1; }
+            }
+        }
+        base_sym += total;
+        endp = s_end[ZK_EXPAND_THREADS - 1];
+        __syncthreads();
+    }
+    /* the trailing literal run is owned by the thread that handled pseudo-hop H */
+    __shared__ uint32_t s_tail;
+    if ((H % ZK_EXPAND_THREADS) == tid) s_tail = tail_lits;
+    __syncthreads();
+    const uint32_t nsym = base_sym;
+    uint32_t nb = zc_block_count(nsym, lim, g.final, s_tail != 0);
+    if (nb > J.P.max_blocks) { if (tid == 0) atomicOr(J.err, (uint32_t)ZE_BLOCK_OVERFLOW); nb = J.P.max_blocks; }
+    /* assemble the block table (FLUSH_BLOCK_ONLY, deflate.c:1538-1547) */
+    for (uint32_t b0 = 0; b0 < nb; b0 += ZK_EXPAND_THREADS) {
+        const uint32_t b = b0 + tid;
+        uint32_t in_start = 0, in_end = 0, p_top = 0;
+        if (b < nb) {
+            in_start = b ? blk[b - 1].bits : g.dict_len;
+            if (b + 1 == nb) { in_end = E; p_top = E; } else { in_end = blk[b].bits; p_top = blk[b].hdr_bits; }
+        }
+        __syncthreads();
+        if (b < nb) {
+            ZcBlock B;
+            B.sym_start = b * lim; B.sym_count = (b + 1 < nb) ? lim : nsym - b * lim;
+            B.in_start = in_start; B.in_len = in_end - in_start;
+            B.flags = ((b + 1 == nb && g.final) ? ZC_BF_LAST : 0u) |
+                      (in_start >= zc_window_base(p_top, E, ZC_MIN_LOOK) ? ZC_BF_CANSTORE : 0u);
+            B.type = 0; B.bits = b + 1 == nb ? 0u : in_end; B.hdr_bits = 0; B.bit_off = 0;
+            blk[b] = B;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { J.nblk[lc] = nb; J.nsym[lc] = nsym; }
 }
 
 /* ------------------------------------------------------------------ k_plan */
@@ -479,7 +809,7 @@ __global__ __launch_bounds__(256) void k_checksum(const uint8_t *in, uint64_t n,
 
 struct ZeWorkspace {
     uint32_t cap_chunks = 0, chunk_size = 0, max_blocks = 0;
-    uint16_t *pdist = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr;
+    uint16_t *pdist = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr; uint32_t *hop = nullptr; uint32_t *nhop = nullptr;
     ZcBlock *blk = nullptr; ZcBlockTab *tab = nullptr;
     uint32_t *nblk = nullptr, *nsym = nullptr; uint64_t *chunk_bytes = nullptr, *sync_bit = nullptr;
     uint64_t pdist_len = 0;
@@ -505,14 +835,14 @@ struct zamd_engine {
 
 static void ws_free(ZeWorkspace &w)
 {
-    hipFree(w.pdist); hipFree(w.rec); hipFree(w.sym); hipFree(w.blk); hipFree(w.tab);
+    hipFree(w.pdist); hipFree(w.rec); hipFree(w.sym); hipFree(w.hop); hipFree(w.nhop); hipFree(w.blk); hipFree(w.tab);
     hipFree(w.nblk); hipFree(w.nsym); hipFree(w.chunk_bytes); hipFree(w.sync_bit);
     w = ZeWorkspace();
 }
 
 static uint64_t ws_bytes_per_chunk(uint32_t chunk_size, uint32_t max_blocks)
 {
-    return 2ull * chunk_size + 8ull * chunk_size + 4ull * chunk_size +
+    return 2ull * chunk_size + 8ull * chunk_size + 4ull * chunk_size + 4ull * chunk_size +
            (uint64_t)max_blocks * (sizeof(ZcBlock) + sizeof(ZcBlockTab)) + 64;
 }
 
@@ -524,6 +854,8 @@ static int ws_ensure(ZeWorkspace &w, uint32_t chunks, uint32_t chunk_size, uint3
     HIPCHK(hipMalloc((void **)&w.pdist, w.pdist_len * 2));
     HIPCHK(hipMalloc((void **)&w.rec, (uint64_t)chunks * chunk_size * 8));
     HIPCHK(hipMalloc((void **)&w.sym, (uint64_t)chunks * chunk_size * 4));
+    HIPCHK(hipMalloc((void **)&w.hop, (uint64_t)chunks * chunk_size * 4));
+    HIPCHK(hipMalloc((void **)&w.nhop, (uint64_t)chunks * 4));
     HIPCHK(hipMalloc((void **)&w.blk, (uint64_t)chunks * max_blocks * sizeof(ZcBlock)));
     HIPCHK(hipMalloc((void **)&w.tab, (uint64_t)chunks * max_blocks * sizeof(ZcBlockTab)));
     HIPCHK(hipMalloc((void **)&w.nblk, (uint64_t)chunks * 4));
@@ -665,7 +997,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     HIPCHK(hipEventRecord(e->ev_scan[1], s0));          /* batch 0's predecessor "scan" */
     const uint32_t tiles = (chunk_size + ZK_TILE - 1) / ZK_TILE;
     for (uint32_t bi = 0; bi < nbatches; bi++) {
-        const int si = (int)(bi & 1u);
+        const int si = getenv("ZAMD_SERIAL") ? 0 : (int)(bi & 1u);
         hipStream_t s = e->st[si];
         ZeWorkspace &w = e->ws[si];
         ZkJob J; memset(&J, 0, sizeof J);
@@ -675,7 +1007,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         ZcChunkGeom g0 = zc_geom(J.n, chunk_size, J.chunk0, finish, J.head);
         J.pdist = w.pdist; J.pdist_base = g0.dstart; J.pdist_len = w.pdist_len;
         J.rec = w.rec; J.rec_base = head_dict_len + J.chunk0 * chunk_size;
-        J.sym = w.sym; J.blk = w.blk; J.tab = w.tab; J.nblk = w.nblk; J.nsym = w.nsym;
+        J.sym = w.sym; J.hop = w.hop; J.nhop = w.nhop; J.arr = (uint32_t *)w.rec; J.blk = w.blk; J.tab = w.tab; J.nblk = w.nblk; J.nsym = w.nsym;
         J.chunk_bytes = w.chunk_bytes; J.sync_bit = w.sync_bit;
         J.chunk_off = d_off; J.running_total = e->d_total;
         J.out32 = (uint32_t *)d_out; J.out_cap = out_cap; J.err = e->d_err;
@@ -692,7 +1024,12 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             tm_end(e, s, slot);
         }
         tm_begin(e, s, 2, &slot);
-        hipLaunchKernelGGL(k_parse, dim3((J.nchunks + 63) / 64), dim3(64), 0, s, J);
+        if (P.parser == ZC_PARSE_SLOW && !getenv("ZAMD_SERIAL_PARSE")) {
+            const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
+            hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
+            hipLaunchKernelGGL(k_hop, dim3(J.nchunks), dim3(64), 0, s, J);
+            hipLaunchKernelGGL(k_expand, dim3(J.nchunks), dim3(ZK_EXPAND_THREADS), 0, s, J);
+        } else hipLaunchKernelGGL(k_parse, dim3(J.nchunks), dim3(64), 0, s, J);
         tm_end(e, s, slot);
         tm_begin(e, s, 3, &slot);
         hipLaunchKernelGGL(k_plan, dim3(P.max_blocks, J.nchunks), dim3(ZK_PLAN_THREADS), 0, s, J);
