@@ -51,11 +51,24 @@ struct ZkJob {
     uint32_t *err;
 };
 
-/* ------------------------------------------------------------------ k_chain */
-__global__ __launch_bounds__(64) void k_chain(ZkJob J)
+/* ------------------------------------------------------------------ k_chain
+ * INSERT_STRING (deflate.c:186-189) for every position of one chunk (plus its
+ * 32 KiB dictionary), head table in LDS.  The strings are inserted in position
+ * order per hash value, which is all the chains need: the 16 wavefronts of the
+ * workgroup split the HASH VALUES between them (hash mod 16), so each wave owns
+ * its slice of the head table and walks the chunk in order, 1024 positions per
+ * round: hashes are computed once per round by all waves together, then every
+ * wave picks its own strings out of the round.  The LDS atomic max returns the
+ * previous (older) position with that hash — lanes and successive steps hold
+ * increasing positions — which becomes the chain link. */
+#define ZK_CHAIN_THREADS 1024
+#define ZK_CHAIN_ROUND   1024u
+__global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
 {
     __shared__ uint32_t head[32768];
-    const uint32_t lane = threadIdx.x;
+    __shared__ uint16_t s_hash[2][ZK_CHAIN_ROUND];
+    __shared__ uint16_t s_link[2][ZK_CHAIN_ROUND];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t c = J.chunk0 + blockIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head);
     const uint32_t E = g.dict_len + g.len;
@@ -67,50 +80,60 @@ __global__ __launch_bounds__(64) void k_chain(ZkJob J)
     const uint8_t *src = J.in + g.dstart;
     uint16_t *pd = J.pdist + (g.dstart - J.pdist_base);
     const uint32_t passes = J.P.hash_bits > 15 ? (1u << (J.P.hash_bits - 15)) : 1u;
+    /* the two aligned words that hold bytes a..a+2, fetched one round ahead */
+    auto fetch = [&](uint32_t a, uint32_t &w0, uint32_t &w1) {
+        w0 = 0; w1 = 0;
+        if (a < Ex) {
+            uint32_t al = a & ~3u;
+            if (g.dstart + al + 8 <= J.n) { w0 = *(const uint32_t *)(src + al); w1 = *(const uint32_t *)(src + al + 4); }
+            else {
+                uint32_t b3 = (uint32_t)src[a] | ((uint32_t)src[a + 1] << 8) | ((uint32_t)src[a + 2] << 16);
+                uint32_t sh = 8u * (a & 3u);
+                w0 = b3 << sh; w1 = sh ? b3 >> (32u - sh) : 0u;
+            }
+        }
+    };
     for (uint32_t pass = 0; pass < passes; pass++) {
-        for (uint32_t i = lane; i < 32768; i += 64) head[i] = 0;
+        for (uint32_t i = tid; i < 32768; i += ZK_CHAIN_THREADS) head[i] = 0;
+        uint32_t w0, w1, buf = 0;
+        fetch(tid, w0, w1);
         __syncthreads();
-        /* four 64-position steps per iteration: all loads first, then the four LDS
-         * atomics back to back (one wave issues LDS operations in order), then the stores */
-        for (uint32_t a0 = 0; a0 < Ex; a0 += 256) {
-            uint32_t h[4]; bool mine[4]; uint32_t old[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t a = a0 + 64u * u + lane;
-                bool valid = a < Ex;
-                uint32_t b3 = 0;
-                if (valid) {
-                    uint32_t al = a & ~3u;
-                    if (g.dstart + al + 8 <= J.n) {
-                        uint32_t w0 = *(const uint32_t *)(src + al), w1 = *(const uint32_t *)(src + al + 4);
-                        b3 = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
-                    } else b3 = (uint32_t)src[a] | ((uint32_t)src[a + 1] << 8) | ((uint32_t)src[a + 2] << 16);
+        for (uint32_t r0 = 0; r0 < Ex; r0 += ZK_CHAIN_ROUND, buf ^= 1u) {
+            /* hashes of this round, one position per thread; 0xffff = not part of this pass */
+            {
+                uint32_t a = r0 + tid, hv = 0xffffu;
+                if (a < Ex) {
+                    uint32_t b3 = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+                    uint32_t h = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
+                    if ((h >> 15) == pass) hv = h & 32767u;
                 }
-                h[u] = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
-                mine[u] = valid && (h[u] >> 15) == pass;
+                s_hash[buf][tid] = (uint16_t)hv;
+                fetch(a + ZK_CHAIN_ROUND, w0, w1);
             }
-            /* LDS atomic max: lanes (and successive steps) hold increasing positions, so the
-             * value returned to a lane is the newest earlier string with the same hash */
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                old[u] = 0;
-                if (mine[u]) old[u] = atomicMax(&head[h[u] & 32767u], a0 + 64u * u + lane + 1);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t a = a0 + 64u * u + lane;
-                if (mine[u]) {
-                    if (old[u] > a) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
-                    uint32_t d = old[u] ? a + 1 - old[u] : 0;
-                    if (d > 32767u) d = 0;
-                    if (a >= out_from) pd[a] = (uint16_t)d;
+            __syncthreads();
+            /* each wave inserts the strings whose hash it owns, in position order */
+#pragma unroll 4
+            for (uint32_t q = 0; q < ZK_CHAIN_ROUND; q += 64) {
+                uint32_t hv = s_hash[buf][q + lane];
+                if (hv != 0xffffu && (hv & 15u) == wv) {
+                    uint32_t a = r0 + q + lane;
+                    uint32_t old = atomicMax(&head[hv], a + 1);
+                    if (old > a) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
+                    uint32_t d = old ? a + 1 - old : 0;
+                    s_link[buf][q + lane] = (uint16_t)(d > 32767u ? 0u : d);
                 }
             }
+            __syncthreads();
+            {
+                uint32_t a = r0 + tid;
+                if (a < Ex && a >= out_from && s_hash[buf][tid] != 0xffffu) pd[a] = s_link[buf][tid];
+            }
+            /* the other buffer pair is written next; this one is reused two rounds on, behind two barriers */
         }
         __syncthreads();
     }
     /* strings without three bytes of input are never inserted */
-    for (uint32_t a = Ex + lane; a < E; a += 64) if (a >= out_from) pd[a] = 0;
+    for (uint32_t a = Ex + tid; a < E; a += ZK_CHAIN_THREADS) if (a >= out_from) pd[a] = 0;
 }
 
 /* ------------------------------------------------------------------ k_match */
@@ -131,6 +154,7 @@ struct LdsPd {
     __device__ uint32_t operator()(uint32_t a) const { uint32_t v = pd[a - a0]; return v == ZK_PD_NONE ? 0u : v; }
 };
 
+template <bool UNAL, int THRESH>
 __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t tiles_per_chunk, int rle)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_lds[ZK_LDS_BYTES / 4];
@@ -206,11 +230,12 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
      * that pass the 3-byte peek are parked and compared in full, together, at the
      * next service point. */
     const uint32_t nice_match = J.P.nice, max_chain = J.P.chain, qb = max_chain >> 2;
-    const uint32_t QNONE = 0xffffffffu;
     const uint32_t la0 = (uint32_t)a0;
-    uint32_t p = t0, cur = t0, best = 2, bdist = 0, qrec = QNONE, scan3 = 0, cap = 0, nice = 0;
+    const uint8_t *s_winb = (const uint8_t *)s_win;
+    uint32_t p = t0, cur = t0, best = 2, bdist = 0, qrec = 0, scan3 = 0, cap = 0, nice = 0;
     int32_t kk = 0;                           /* candidates examined minus max_chain: negative while budget remains */
     int32_t walking = 0, parked = 0;          /* sign masks: -1 / 0 */
+    uint32_t wcur = 0, wend = 0;              /* this wave's ticket of unclaimed tile positions */
     bool exhausted = false;
     for (;;) {
         /* ---- full comparisons of parked candidates (zc_match_extend, then zc_match_advance) */
@@ -224,84 +249,97 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
             if (len > cap) len = cap;
             bool fin = false;
             /* the step that parked this walk already counted the candidate */
+            const uint32_t k = (uint32_t)(kk + (int32_t)max_chain);
             if (len > best) {
                 best = len; bdist = p - cur;
+                if (k <= qb) qrec = best | (bdist << 16);   /* best of the first max_chain/4 candidates */
                 if (len >= nice) fin = true;
                 else scan3 = win.load4(p + len - 2u) & 0x00ffffffu;
             }
             if (!fin) {
                 uint32_t d = pd(cur);
-                if ((uint32_t)(kk + (int32_t)max_chain) == qb) qrec = best >= 3u ? (best | (bdist << 16)) : 0u;
                 if (kk >= 0 || d == 0 || d >= cur) fin = true;
                 else { cur -= d; fin = p - cur >= ZC_MAX_DIST; }
             }
             parked = 0; walking = -1;
             if (fin) {
-                uint32_t k = (uint32_t)(kk + (int32_t)max_chain);
                 uint32_t full = best >= 3u ? (best | (bdist << 16)) : 0u;
-                uint32_t rq = qb == 0 ? 0u : ((qrec != QNONE && k > qb) ? qrec : full);
+                uint32_t rq = qb == 0 ? 0u : (k > qb ? qrec : full);
                 rec[p - t0] = make_uint2(full, rq);
                 walking = 0;
             }
         }
-        /* ---- refill idle lanes */
-        unsigned long long idle = __ballot(walking == 0);
-        if (idle != 0ull && !exhausted) {
-            uint32_t cnt = (uint32_t)__popcll(idle), base = 0;
-            if (lane == 0) base = atomicAdd(&s_next, cnt);
-            base = __shfl(base, 0);
-            if (base + cnt >= tlen) exhausted = true;
-            if (walking == 0) {
-                uint32_t idx = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (idx < tlen) {
-                    ZcMatchState st;
-                    if (zc_match_init(win, pd, t0 + idx, E, g.corner, nice_match, st)) {
-                        p = st.p; cur = st.cur; kk = -(int32_t)max_chain; best = 2; bdist = 0; qrec = QNONE;
-                        scan3 = st.scan3; cap = st.cap; nice = st.nice;
-                        walking = -1;
-                    } else rec[idx] = make_uint2(0u, 0u);
-                }
+        /* ---- refill idle lanes from the wave's ticket (64 positions per LDS atomic) */
+        for (int pass = 0; pass < 2; pass++) {
+            unsigned long long idle = __ballot(walking == 0);
+            if (idle == 0ull) break;
+            if (wcur == wend) {
+                if (exhausted) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_next, 64u);
+                base = __shfl(base, 0);
+                wcur = base; wend = base + 64u < tlen ? base + 64u : tlen;
+                if (base + 64u >= tlen) exhausted = true;
+                if (base >= tlen) { wcur = wend = 0; break; }
             }
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t take = (uint32_t)__popcll(idle) < wend - wcur ? (uint32_t)__popcll(idle) : wend - wcur;
+            if (walking == 0 && rank < take) {
+                const uint32_t idx = wcur + rank;
+                ZcMatchState st;
+                if (zc_match_init(win, pd, t0 + idx, E, g.corner, nice_match, st)) {
+                    p = st.p; cur = st.cur; kk = -(int32_t)max_chain; best = 2; bdist = 0; qrec = 0;
+                    scan3 = st.scan3; cap = st.cap; nice = st.nice;
+                    walking = -1;
+                } else rec[idx] = make_uint2(0u, 0u);
+            }
+            wcur += take;
         }
-        if (__ballot(walking < 0) == 0ull) { if (exhausted) break; continue; }
+        if (__ballot(walking < 0) == 0ull) { if (exhausted && wcur == wend) break; continue; }
         /* ---- candidate steps until a quarter of the lanes need service */
         const uint32_t full_now = best >= 3u ? (best | (bdist << 16)) : 0u;   /* best is fixed while walking */
-        const uint32_t boff = best - 2u;
         const uint32_t pout = p - t0;
         const int32_t lim = (int32_t)(p < ZC_MAX_DIST ? p : ZC_MAX_DIST);      /* stop once the distance reaches this */
-        const int32_t kq = (int32_t)qb - (int32_t)max_chain;
-        uint32_t curi = cur - la0;            /* LDS-relative index of the candidate */
+        const uint8_t *peek = s_winb + (best - 2u) - la0;   /* + candidate a-coordinate = address of its bytes best-2.. */
+        const uint32_t peek_off = (best - 2u) - la0;
+        const uint16_t *link = s_pd - la0;
+        uint32_t c = cur;                     /* candidate */
         int32_t dist = (int32_t)(p - cur);
         int32_t wm = walking;
 #pragma unroll 1
-        for (int it = 0; it < 64; it++) {
-            const uint32_t ac = curi + boff;
-            const uint32_t wi = ac >> 2;
-            const uint32_t w0 = s_win[wi], w1 = s_win[wi + 1];
-            const int32_t d = (int32_t)s_pd[curi];
-            const uint32_t x = (__builtin_amdgcn_alignbyte(w1, w0, ac & 3u) & 0x00ffffffu) ^ scan3;
-            const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
-            const int32_t hit = (int32_t)(x - 1u) & wm;      /* negative iff walking and matched */
-            kk -= wm;                                         /* count the candidate */
-            qrec = (kk == kq && wm < 0) ? full_now : qrec;   /* a parked walk redoes this after its comparison */
-            const int32_t dn = dist + d;
-            const int32_t go = (dn - lim) & kk & nohit & wm; /* negative iff the walk continues */
-            const int32_t fin = nohit & wm & ~go;             /* negative iff the walk ends here */
-            if (fin < 0) {
-                uint32_t k = (uint32_t)(kk - kq) + qb;
-                uint32_t rq = qb == 0 ? 0u : ((qrec != QNONE && k > qb) ? qrec : full_now);
-                rec[pout] = make_uint2(full_now, rq);
+        for (int it = 0; it < 32; it++) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                uint32_t v;
+                if (UNAL) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
+                else {
+                    const uint32_t ac = c + peek_off;
+                    const uint32_t wi = ac >> 2;
+                    v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], ac & 3u);
+                }
+                const int32_t d = (int32_t)link[c];
+                const uint32_t x = (v & 0x00ffffffu) ^ scan3;
+                const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
+                const int32_t hit = (int32_t)(x - 1u) & wm;      /* negative iff walking and matched */
+                kk -= wm;                                         /* count the candidate */
+                const int32_t dn = dist + d;
+                const int32_t go = (dn - lim) & kk & nohit & wm; /* negative iff the walk continues */
+                const int32_t fin = nohit & wm & ~go;             /* negative iff the walk ends here */
+                if (fin < 0) {
+                    uint32_t k = (uint32_t)(kk + (int32_t)max_chain);
+                    uint32_t rq = qb == 0 ? 0u : (k > qb ? qrec : full_now);
+                    rec[pout] = make_uint2(full_now, rq);
+                }
+                dist = go < 0 ? dn : dist;
+                c = go < 0 ? c - (uint32_t)d : c;
+                parked |= hit;
+                wm = go >> 31;
             }
-            dist = go < 0 ? dn : dist;
-            curi = go < 0 ? curi - (uint32_t)d : curi;
-            parked |= hit;
-            wm = go >> 31;
-            if (__popcll(__ballot(wm == 0)) >= 16) break;
+            if (__popcll(__ballot(wm == 0)) >= THRESH) break;
         }
-        cur = curi + la0;
-        walking = wm | (parked >> 31);        /* parked walks are still owned by the lane */
+        cur = c;
         parked >>= 31;
-        if (parked < 0) walking = 0 | walking;
+        walking = wm | parked;                /* parked walks are still owned by the lane */
     }
 }
 
@@ -1015,12 +1053,21 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (bi == 1) HIPCHK(hipStreamWaitEvent(s, e->ev_scan[1], 0));   /* memsets on stream 0 */
         if (P.parser == ZC_PARSE_SLOW) {
             tm_begin(e, s, 0, &slot);
-            hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(64), 0, s, J);
+            hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(ZK_CHAIN_THREADS), 0, s, J);
             tm_end(e, s, slot);
         }
         if (P.parser == ZC_PARSE_SLOW || P.parser == ZC_PARSE_RLE) {
             tm_begin(e, s, 1, &slot);
-            hipLaunchKernelGGL(k_match, dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles, P.parser == ZC_PARSE_RLE ? 1 : 0);
+            {
+                static int mv = getenv("ZAMD_MV") ? atoi(getenv("ZAMD_MV")) : 0;
+                int rle = P.parser == ZC_PARSE_RLE ? 1 : 0;
+                dim3 grid(J.nchunks * tiles), blk(ZK_MATCH_THREADS);
+                if (mv == 1) hipLaunchKernelGGL((k_match<true, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 2) hipLaunchKernelGGL((k_match<false, 12>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 3) hipLaunchKernelGGL((k_match<false, 44>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 4) hipLaunchKernelGGL((k_match<false, 20>), grid, blk, 0, s, J, tiles, rle);
+                else hipLaunchKernelGGL((k_match<false, 32>), grid, blk, 0, s, J, tiles, rle);
+            }
             tm_end(e, s, slot);
         }
         tm_begin(e, s, 2, &slot);
