@@ -125,8 +125,18 @@ def main():
         avg_ms = match_ms / match_launches
         alg_bytes = (n / match_launches) * (1.0 + 1.0 / ratio)    # N_in + N_out of one launch's batch
         ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM traffic per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+        # rocprofv3 runs, gfx950 correction applied): bytes per input byte x the input bytes of one launch
+        traffic = None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            per_byte = [v["hbm_bytes_per_input_byte"] for k, v in prof["kernels"].items() if k.startswith("k_match")][0]
+            traffic = round(per_byte * (n / match_launches) / 1e9, 3)
+        except Exception:
+            pass
         roofline = {"bound": "hbm", "kernel": "k_match", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(ach / 8000.0, 6), "traffic": None,
+                    "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_unit": "GB per launch",
+                    "algorithmic_gb_per_launch": round(alg_bytes / 1e9, 3),
                     "avg_launch_ms": round(avg_ms, 3), "launches": match_launches}
 
     if rank == 0:
