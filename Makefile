@@ -2,12 +2,15 @@
 HIPCC ?= hipcc
 ARCH ?= gfx950
 SRCS = zlib_amd/csrc/zamd_engine.hip zlib_amd/csrc/zamd_corpus.cpp
-HDRS = zlib_amd/csrc/zamd_core.h include/zamd.h
+HDRS = zlib_amd/csrc/zamd_core.h zlib_amd/csrc/zamd_inflate_impl.h include/zamd.h
 
-all: zlib_amd/libzamd.so oracle
+all: zlib_amd/libzamd.so zlib_amd/libzamd_z.so oracle
 
 zlib_amd/libzamd.so: $(SRCS) $(HDRS)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -o $@ $(SRCS)
+
+zlib_amd/libzamd_z.so: zlib_amd/csrc/zamd_zlib.cpp include/zamd_zlib.h include/zamd.h zlib_amd/libzamd.so
+	g++ -O2 -std=c++17 -fPIC -shared -pthread -o $@ zlib_amd/csrc/zamd_zlib.cpp -Lzlib_amd -lzamd -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle
@@ -17,5 +20,5 @@ tests/host_emul: tests/host_emul.cpp zlib_amd/csrc/zamd_core.h oracle/zoracle.c
 	g++ -O2 -std=c++17 -I zlib_amd/csrc -I oracle -o $@ tests/host_emul.cpp /tmp/zoracle_emul.o
 
 clean:
-	rm -f zlib_amd/libzamd.so tests/host_emul
+	rm -f zlib_amd/libzamd.so zlib_amd/libzamd_z.so tests/host_emul
 .PHONY: all oracle clean

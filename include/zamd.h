@@ -99,15 +99,53 @@ uint32_t zamd_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);
  * occupies d_comp[chunk_off[i], chunk_off[i+1]) and inflates to chunk_size bytes
  * (the last one to the remainder of n_out).  Replaces a loop of
  * inflateSetDictionary + inflate(Z_SYNC_FLUSH) per chunk (inflate.c:605, 1291;
- * the access pattern of examples/zran.c:249-349).  Returns ZAMD_DATA_ERROR and
- * the failing chunk in *bad_chunk if a stream is invalid.
+ * the access pattern of examples/zran.c:249-349).  d_comp must be 4-byte aligned
+ * and readable up to the next multiple of 4 bytes, d_out 16-byte aligned,
+ * chunk_size a multiple of 8.  Returns ZAMD_DATA_ERROR and the failing chunk in
+ * *bad_chunk if a stream is invalid (zamd_inflate_last_error gives the reason).
  */
 int zamd_inflate_dev(zamd_engine *e, const void *d_comp, const uint64_t *d_chunk_off, uint64_t n_chunks,
                      uint32_t chunk_size, void *d_out, uint64_t n_out, int64_t *bad_chunk);
 
+/* The same for one shard of a larger stream: d_chunk_off holds offsets relative
+ * to d_comp (comp_bytes long); d_head_window (device, 32768 bytes, or NULL for
+ * the shard that starts the stream) is the inflated data in front of the shard,
+ * i.e. the last 32 KiB produced by the previous shard. */
+int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                           uint32_t chunk_size, const void *d_head_window, void *d_out, uint64_t n_out, int64_t *bad_chunk);
+
+/*
+ * General form: inflate a list of segments of one raw deflate stream, one GPU
+ * wavefront per segment.  A segment starts at bit in_bit (a block boundary) and
+ * may read up to bit in_end_bit; it decodes whole blocks until the final block,
+ * the end of its input, or (mode & ZAMD_INF_SYNCSTOP) an empty stored block.
+ * With d_out == NULL only lengths are computed; otherwise segment i writes
+ * d_out[out_off, out_off + out_len) (out_off ascending, regions disjoint,
+ * out_len <= out_cap) and may refer to the win_avail (<= 32768) bytes in front of
+ * out_off — which other segments of the same call produce, or d_head_window
+ * holds for positions before d_out[0].  On return every segment carries
+ * out_len / end_bit of the last complete block, final_seen, and status:
+ * 0 = stopped at in_end_bit, 1 = final block done, 2 = stopped at a sync marker,
+ * 3 = input ended inside a block, >= 16 = data error (zamd_inflate_message).
+ * This is what inflate() of include/zamd_zlib.h is built on (inflate.c:605).
+ */
+typedef struct zamd_inflate_seg {
+    uint64_t in_bit, in_end_bit, out_off, out_cap;
+    uint32_t win_avail, mode;
+    uint64_t out_len, end_bit;          /* results */
+    uint32_t status, final_seen;        /* results */
+} zamd_inflate_seg;
+#define ZAMD_INF_SYNCSTOP 1u
+#define ZAMD_INF_EXACT    2u            /* out_len must come out equal to out_cap */
+int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, zamd_inflate_seg *segs, uint64_t nseg,
+                              const void *d_head_window, void *d_out, uint64_t out_bytes);
+const char *zamd_inflate_message(uint32_t status);      /* the reference's msg strings, inflate.c:859-1202 */
+int zamd_inflate_last_error(zamd_engine *e, int64_t *segment, uint32_t *status);
+
 /* Timing of the last zamd_deflate_dev call, measured with HIP events on the
  * engine's own streams: `which` 0 = chain build, 1 = match search, 2 = parse,
- * 3 = block planning, 4 = layout, 5 = bit emission, 6 = whole call.
+ * 3 = block planning, 4 = layout, 5 = bit emission, 6 = whole call; of the last
+ * inflate call: 7 = decode, 8 = window resolution.
  * Returns the summed milliseconds; *launches receives the number of launches. */
 double zamd_last_timing_ms(zamd_engine *e, int which, int *launches);
 

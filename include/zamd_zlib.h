@@ -1,0 +1,149 @@
+/*
+ * zamd_zlib.h — the zlib 1.2.8 stream API as exported by libzamd_z.so.
+ *
+ * Declarations are binary compatible with the reference's zlib.h (types
+ * zconf.h:368-490, z_stream zlib.h:85-104, gz_header zlib.h:109-129, constants
+ * zlib.h:161-209): a program compiled against the reference header can be linked
+ * against this library instead of libz.  Only the entry points listed here are
+ * provided; every one names the reference function it replaces.
+ *
+ * Compression runs on the GPU through the engine in zamd.h: deflate() buffers
+ * input on the host and compresses it as dictionary-primed chunks (default
+ * 1 MiB, each ending on a Z_SYNC_FLUSH marker), so the stream is valid zlib /
+ * gzip / raw deflate and every chunk equals the reference's output for that
+ * chunk, but a multi-chunk stream is not byte-identical to a single reference
+ * stream.  Inputs of at most one chunk compress to exactly the reference's bytes.
+ */
+#ifndef ZAMD_ZLIB_H
+#define ZAMD_ZLIB_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZLIB_VERSION "1.2.8"
+#define ZLIB_VERNUM 0x1280
+
+typedef unsigned char Byte;
+typedef unsigned int uInt;
+typedef unsigned long uLong;
+typedef Byte Bytef;
+typedef void *voidpf;
+typedef void *voidp;
+typedef uLong uLongf;
+typedef long z_off_t;
+typedef long long z_off64_t;
+typedef unsigned int z_crc_t;
+
+typedef voidpf (*alloc_func)(voidpf opaque, uInt items, uInt size);
+typedef void (*free_func)(voidpf opaque, voidpf address);
+struct internal_state;
+
+typedef struct z_stream_s {            /* zlib.h:85-104 */
+    const Bytef *next_in; uInt avail_in; uLong total_in;
+    Bytef *next_out; uInt avail_out; uLong total_out;
+    const char *msg;
+    struct internal_state *state;
+    alloc_func zalloc; free_func zfree; voidpf opaque;
+    int data_type; uLong adler; uLong reserved;
+} z_stream;
+typedef z_stream *z_streamp;
+
+typedef struct gz_header_s {           /* zlib.h:109-129 */
+    int text; uLong time; int xflags; int os;
+    Bytef *extra; uInt extra_len; uInt extra_max;
+    Bytef *name; uInt name_max;
+    Bytef *comment; uInt comm_max;
+    int hcrc; int done;
+} gz_header;
+typedef gz_header *gz_headerp;
+
+/* zlib.h:161-209 */
+#define Z_NO_FLUSH 0
+#define Z_PARTIAL_FLUSH 1
+#define Z_SYNC_FLUSH 2
+#define Z_FULL_FLUSH 3
+#define Z_FINISH 4
+#define Z_BLOCK 5
+#define Z_TREES 6
+#define Z_OK 0
+#define Z_STREAM_END 1
+#define Z_NEED_DICT 2
+#define Z_ERRNO (-1)
+#define Z_STREAM_ERROR (-2)
+#define Z_DATA_ERROR (-3)
+#define Z_MEM_ERROR (-4)
+#define Z_BUF_ERROR (-5)
+#define Z_VERSION_ERROR (-6)
+#define Z_NO_COMPRESSION 0
+#define Z_BEST_SPEED 1
+#define Z_BEST_COMPRESSION 9
+#define Z_DEFAULT_COMPRESSION (-1)
+#define Z_FILTERED 1
+#define Z_HUFFMAN_ONLY 2
+#define Z_RLE 3
+#define Z_FIXED 4
+#define Z_DEFAULT_STRATEGY 0
+#define Z_BINARY 0
+#define Z_TEXT 1
+#define Z_UNKNOWN 2
+#define Z_DEFLATED 8
+#define Z_NULL 0
+
+const char *zlibVersion(void);                                                  /* zutil.c:30 */
+uLong zlibCompileFlags(void);                                                   /* zutil.c:35 */
+const char *zError(int err);                                                    /* zutil.c:136 */
+
+/* deflate side: deflate.c:201-1067 */
+int deflateInit_(z_streamp strm, int level, const char *version, int stream_size);                  /* :201 */
+int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int memLevel,
+                  int strategy, const char *version, int stream_size);                              /* :213 */
+int deflate(z_streamp strm, int flush);                                                             /* :665 */
+int deflateEnd(z_streamp strm);                                                                     /* :979 */
+int deflateReset(z_streamp strm);                                                                   /* :427 */
+int deflateResetKeep(z_streamp strm);                                                               /* :392 */
+uLong deflateBound(z_streamp strm, uLong sourceLen);                                                /* :566 */
+int deflateParams(z_streamp strm, int level, int strategy);                                         /* :490 */
+int deflatePending(z_streamp strm, unsigned *pending, int *bits);                                   /* :450 */
+int deflateSetHeader(z_streamp strm, gz_headerp head);                                              /* :439 */
+int deflateCopy(z_streamp dest, z_streamp source);                                                  /* :1014 */
+/* accepted by the reference, not supported by the chunked engine: return Z_STREAM_ERROR */
+int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength);                 /* :323 */
+int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain);     /* :531 */
+int deflatePrime(z_streamp strm, int bits, int value);                                              /* :464 */
+
+/* inflate side: inflate.c:104-1512 */
+int inflateInit_(z_streamp strm, const char *version, int stream_size);                             /* :222 */
+int inflateInit2_(z_streamp strm, int windowBits, const char *version, int stream_size);            /* :180 */
+int inflate(z_streamp strm, int flush);                                                             /* :605 */
+int inflateEnd(z_streamp strm);                                                                     /* :1254 */
+int inflateReset(z_streamp strm);                                                                   /* :129 */
+int inflateReset2(z_streamp strm, int windowBits);                                                  /* :141 */
+
+/* one-shot utilities: compress.c:22-80, uncompr.c:24-59 */
+int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen);
+int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level);
+uLong compressBound(uLong sourceLen);
+int uncompress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen);
+
+/* checksums: adler32.c:65-179, crc32.c:204-425 */
+uLong adler32(uLong adler, const Bytef *buf, uInt len);
+uLong crc32(uLong crc, const Bytef *buf, uInt len);
+uLong adler32_combine(uLong adler1, uLong adler2, z_off_t len2);
+uLong adler32_combine64(uLong adler1, uLong adler2, z_off64_t len2);
+uLong crc32_combine(uLong crc1, uLong crc2, z_off_t len2);
+uLong crc32_combine64(uLong crc1, uLong crc2, z_off64_t len2);
+const z_crc_t *get_crc_table(void);
+
+#define deflateInit(strm, level) deflateInit_((strm), (level), ZLIB_VERSION, (int)sizeof(z_stream))
+#define deflateInit2(strm, level, method, windowBits, memLevel, strategy) \
+    deflateInit2_((strm), (level), (method), (windowBits), (memLevel), (strategy), ZLIB_VERSION, (int)sizeof(z_stream))
+#define inflateInit(strm) inflateInit_((strm), ZLIB_VERSION, (int)sizeof(z_stream))
+#define inflateInit2(strm, windowBits) inflateInit2_((strm), (windowBits), ZLIB_VERSION, (int)sizeof(z_stream))
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,150 @@
+"""Batch inflate on the GPU (through the C ABI): round trips of the engine's own
+chunked streams, foreign single streams, the reference's raw-inflate test vectors
+and the segment interface.  Byte work: the bar is bit-exact."""
+import json
+import os
+import zlib
+
+import pytest
+
+import _oracle as O
+import zlib_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VEC = json.load(open(os.path.join(ROOT, "tests", "golden", "inflate_vectors.json")))["raw"]
+
+
+def _one_segment(engine, comp, out_cap=1 << 22, **kw):
+    seg = dict(in_bit=0, in_end_bit=8 * len(comp), out_off=0, out_cap=out_cap, win_avail=0, mode=0)
+    seg.update(kw)
+    return seg
+
+
+@pytest.mark.parametrize("v", VEC, ids=lambda v: v["hex"][:20].replace(" ", ""))
+def test_reference_raw_vectors(engine, v):
+    comp = bytes.fromhex(v["hex"].replace(" ", ""))
+    rc, want, used, msg = O.inflate_raw(comp, b"", 1 << 20)
+    assert msg == v["msg"]
+    res, _ = engine.inflate_segments(comp, [_one_segment(engine, comp)])
+    r = res[0]
+    if v["msg"] is None:
+        assert r["status"] == 1 and r["final_seen"] == 1
+        assert r["out_len"] == len(want)
+        res, out = engine.inflate_segments(comp, [_one_segment(engine, comp, out_cap=len(want))], out_bytes=max(16, len(want)))
+        assert res[0]["status"] == 1
+        assert out[:len(want)] == want
+    else:
+        assert r["status"] >= 16
+        assert r["msg"] == v["msg"]
+
+
+CASES = []
+for kind in range(5):
+    CASES.append((kind, (1 << 20) * 3 + 4321, 6, 0, 1 << 20))
+    CASES.append((kind, 700001, 9, 0, 65536))
+for strat in (1, 2, 3, 4):
+    CASES.append((3, 500001, 6, strat, 1 << 18))
+for n in (0, 1, 5, 258, 32768, 32769, 65536, 65537, 100000):
+    CASES.append((0, n, 6, 0, 32768))
+    CASES.append((4, n, 4, 0, 65536))
+
+
+@pytest.mark.parametrize("kind,n,level,strategy,chunk", CASES)
+def test_round_trip_of_chunked_streams(engine, kind, n, level, strategy, chunk):
+    data = O.corpus(n, kind, 23 + kind)
+    stream, offs = engine.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk)
+    out = engine.inflate_chunks(stream, offs, n, chunk_size=chunk)
+    assert out == data
+
+
+def test_long_range_window_propagation(engine):
+    # every chunk starts by copying from the previous one, and runs of one byte cross many chunks
+    data = b"\0" * 200000 + O.corpus(100000, 0, 3) + b"\xff" * 150000 + O.corpus(70000, 0, 3) * 3
+    for chunk in (32768, 65536):
+        stream, offs = engine.deflate_chunks(data, level=9, chunk_size=chunk)
+        assert engine.inflate_chunks(stream, offs, len(data), chunk_size=chunk) == data
+
+
+@pytest.mark.parametrize("level,wbits_data", [(1, 0), (6, 1), (9, 4)])
+def test_foreign_single_stream(engine, level, wbits_data):
+    # a stream that was not cut into chunks (system zlib as the producer): one segment, one wavefront
+    data = O.corpus(600000, wbits_data, 5)
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    res, _ = engine.inflate_segments(comp, [_one_segment(engine, comp)])
+    assert res[0]["status"] == 1 and res[0]["out_len"] == len(data)
+    assert res[0]["end_bit"] <= 8 * len(comp) and res[0]["end_bit"] > 8 * (len(comp) - 1)
+    res, out = engine.inflate_segments(comp, [_one_segment(engine, comp, out_cap=len(data))], out_bytes=len(data))
+    assert out == data
+
+
+def test_segments_stop_at_sync_markers_and_chain(engine):
+    data = O.corpus(300000, 4, 9)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    pieces = [data[0:1000], data[1000:120000], data[120000:120001], data[120001:]]
+    comp, cuts = b"", [0]
+    for i, p in enumerate(pieces):
+        comp += c.compress(p) + c.flush(zlib.Z_SYNC_FLUSH if i < len(pieces) - 1 else zlib.Z_FINISH)
+        cuts.append(len(comp))
+    segs = [dict(in_bit=8 * cuts[i], in_end_bit=8 * len(comp), out_off=0, out_cap=1 << 30, win_avail=min(32768, sum(map(len, pieces[:i]))),
+                 mode=zlib_amd.INF_SYNCSTOP) for i in range(len(pieces))]
+    res, _ = engine.inflate_segments(comp, segs)
+    for i, r in enumerate(res):
+        assert r["status"] == (2 if i < len(pieces) - 1 else 1), r
+        assert r["out_len"] == len(pieces[i])
+        assert r["end_bit"] == 8 * cuts[i + 1] or i == len(pieces) - 1
+    off = 0
+    for s, r in zip(segs, res):
+        s["out_off"], s["out_cap"], s["in_end_bit"] = off, r["out_len"], r["end_bit"]
+        off += r["out_len"]
+    res, out = engine.inflate_segments(comp, segs, out_bytes=len(data))
+    assert out == data
+
+
+def test_truncated_input_reports_last_complete_block(engine):
+    data = O.corpus(400000, 0, 2)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    cut = len(comp) * 2 // 3
+    res, _ = engine.inflate_segments(comp[:cut], [_one_segment(engine, comp[:cut])])
+    r = res[0]
+    assert r["status"] == 3
+    assert 0 < r["out_len"] < len(data) and r["end_bit"] <= 8 * cut
+    # the reported prefix is exactly what a serial decoder produces up to that block boundary
+    seg = _one_segment(engine, comp[:cut], out_cap=r["out_len"], in_end_bit=r["end_bit"])
+    res2, out = engine.inflate_segments(comp[:cut], [seg], out_bytes=r["out_len"])
+    assert res2[0]["status"] == 0
+    assert out == data[:r["out_len"]]
+
+
+def test_corrupt_chunk_is_reported(engine):
+    data = O.corpus(300000, 0, 8)
+    stream, offs = engine.deflate_chunks(data, level=6, chunk_size=65536)
+    hits = 0
+    for delta in range(0, 40, 3):
+        bad = bytearray(stream)
+        mid = (offs[2] + offs[3]) // 2 + delta
+        bad[mid] ^= 0x55
+        try:
+            out = engine.inflate_chunks(bytes(bad), offs, len(data), chunk_size=65536)
+        except zlib_amd.ZamdError as e:
+            assert e.code == zlib_amd.Z_DATA_ERROR and e.segment == 2 and e.msg
+            hits += 1
+            continue
+        # raw deflate carries no checksum: a flipped literal can still be a valid stream of the same length,
+        # but then only chunk 2 and what copies from it may differ
+        assert out[:2 * 65536] == data[:2 * 65536] and out != data
+    assert hits > 0
+
+
+def test_shard_with_head_window(engine):
+    data = O.corpus(500000, 4, 12)
+    chunk = 65536
+    stream, offs = engine.deflate_chunks(data, level=6, chunk_size=chunk)
+    k = 3                                   # second shard starts at chunk k
+    sub = stream[offs[k]:]
+    sub_offs = [o - offs[k] for o in offs[k:]]
+    head = data[k * chunk - 32768:k * chunk]
+    out = engine.inflate_chunks(sub, sub_offs, len(data) - k * chunk, chunk_size=chunk, head_window=head)
+    assert out == data[k * chunk:]

@@ -170,3 +170,13 @@ def test_oracle_inflate_round_trip_and_errors():
 def test_oracle_against_reference_build():
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "fuzz_vs_ref"), "150", "2024", "150000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_inflate_oracle_on_reference_raw_vectors():
+    """The raw-inflate vectors of the reference's own test (test/infcover.c:583-610)."""
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "inflate_vectors.json")))["raw"]
+    for v in vec:
+        comp = bytes.fromhex(v["hex"].replace(" ", ""))
+        rc, out, used, msg = O.inflate_raw(comp, b"", 1 << 20)
+        assert msg == v["msg"], v
+        assert (rc == 0) == (v["msg"] is None)

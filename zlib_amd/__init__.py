@@ -23,9 +23,19 @@ _lib = None
 
 
 class ZamdError(RuntimeError):
-    def __init__(self, code: int, what: str):
-        super().__init__(f"{what} failed with code {code}")
-        self.code = code
+    def __init__(self, code: int, what: str, msg: str = "", segment: int = -1):
+        super().__init__(f"{what} failed with code {code}" + (f": {msg} (segment {segment})" if msg else ""))
+        self.code, self.msg, self.segment = code, msg, segment
+
+
+class InflateSeg(C.Structure):
+    """zamd_inflate_seg of include/zamd.h."""
+    _fields_ = [("in_bit", C.c_uint64), ("in_end_bit", C.c_uint64), ("out_off", C.c_uint64), ("out_cap", C.c_uint64),
+                ("win_avail", C.c_uint32), ("mode", C.c_uint32), ("out_len", C.c_uint64), ("end_bit", C.c_uint64),
+                ("status", C.c_uint32), ("final_seen", C.c_uint32)]
+
+
+INF_SYNCSTOP, INF_EXACT = 1, 2
 
 
 def load_library() -> C.CDLL:
@@ -59,6 +69,14 @@ def load_library() -> C.CDLL:
     lib.zamd_crc32_combine.restype = u32
     lib.zamd_inflate_dev.argtypes = [vp, vp, vp, u64, u32, vp, u64, C.POINTER(C.c_int64)]
     lib.zamd_inflate_dev.restype = i32
+    lib.zamd_inflate_shard_dev.argtypes = [vp, vp, u64, vp, u64, u32, vp, vp, u64, C.POINTER(C.c_int64)]
+    lib.zamd_inflate_shard_dev.restype = i32
+    lib.zamd_inflate_segments_dev.argtypes = [vp, vp, u64, C.POINTER(InflateSeg), u64, vp, vp, u64]
+    lib.zamd_inflate_segments_dev.restype = i32
+    lib.zamd_inflate_message.argtypes = [u32]
+    lib.zamd_inflate_message.restype = C.c_char_p
+    lib.zamd_inflate_last_error.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(u32)]
+    lib.zamd_inflate_last_error.restype = i32
     lib.zamd_last_timing_ms.argtypes = [vp, i32, C.POINTER(i32)]
     lib.zamd_last_timing_ms.restype = C.c_double
     lib.zamd_corpus_fill.argtypes = [vp, u64, i32, u64]
@@ -243,6 +261,74 @@ class Engine:
             return self.crc32_dev(d.ptr, n, value)
         finally:
             d.free()
+
+    # -- inflate ------------------------------------------------------------------------
+    def _inflate_error(self, rc: int, what: str) -> ZamdError:
+        seg, st = C.c_int64(-1), C.c_uint32(0)
+        self.lib.zamd_inflate_last_error(self.handle, C.byref(seg), C.byref(st))
+        return ZamdError(rc, what, self.lib.zamd_inflate_message(st.value).decode(), seg.value)
+
+    def inflate_dev(self, d_comp: int, d_chunk_off: int, n_chunks: int, d_out: int, n_out: int, *,
+                    chunk_size: int = 1 << 20, comp_bytes: Optional[int] = None, d_head_window: int = 0) -> None:
+        """Batch inflate of a chunk-indexed raw deflate stream (device pointers)."""
+        bad = C.c_int64(-1)
+        if comp_bytes is None:
+            rc = self.lib.zamd_inflate_dev(self.handle, d_comp, d_chunk_off, n_chunks, chunk_size, d_out, n_out, C.byref(bad))
+        else:
+            rc = self.lib.zamd_inflate_shard_dev(self.handle, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size,
+                                                 d_head_window or None, d_out, n_out, C.byref(bad))
+        if rc == Z_DATA_ERROR:
+            raise self._inflate_error(rc, "zamd_inflate_dev")
+        _chk(rc, "zamd_inflate_dev")
+
+    def inflate_chunks(self, stream, offsets, n_out: int, *, chunk_size: int = 1 << 20, head_window=None) -> bytes:
+        """Host convenience around inflate_dev: offsets = chunk offsets + total, as deflate_chunks returns."""
+        import struct
+        n_chunks = len(offsets) - 1
+        d_comp = self.alloc(len(stream) + 16)
+        d_off = self.alloc(8 * len(offsets))
+        d_out = self.alloc(max(n_out, 16))
+        d_head = self.alloc(32768) if head_window is not None else None
+        try:
+            d_comp.upload(stream)
+            d_off.upload(struct.pack(f"<{len(offsets)}Q", *offsets))
+            if d_head is not None:
+                d_head.upload(head_window)
+            self.inflate_dev(d_comp.ptr, d_off.ptr, n_chunks, d_out.ptr, n_out, chunk_size=chunk_size,
+                             comp_bytes=len(stream), d_head_window=d_head.ptr if d_head else 0)
+            return bytes(d_out.download(n_out))
+        finally:
+            d_comp.free(); d_off.free(); d_out.free()
+            if d_head is not None:
+                d_head.free()
+
+    def inflate_segments(self, stream, segs, *, out_bytes: int = 0, head_window=None):
+        """zamd_inflate_segments_dev on host bytes.  segs: list of dicts with the input fields of InflateSeg.
+        Returns (list of result dicts, output bytes or None when out_bytes == 0)."""
+        arr = (InflateSeg * len(segs))()
+        for a, sdict in zip(arr, segs):
+            for k, v in sdict.items():
+                setattr(a, k, v)
+        d_comp = self.alloc(len(stream) + 16)
+        d_out = self.alloc(out_bytes) if out_bytes else None
+        d_head = self.alloc(32768) if head_window is not None else None
+        try:
+            d_comp.upload(stream)
+            if d_head is not None:
+                d_head.upload(head_window)
+            _chk(self.lib.zamd_inflate_segments_dev(self.handle, d_comp.ptr, len(stream), arr, len(segs),
+                                                    d_head.ptr if d_head else None, d_out.ptr if d_out else None, out_bytes),
+                 "zamd_inflate_segments_dev")
+            res = [{f[0]: getattr(a, f[0]) for f in InflateSeg._fields_} for a in arr]
+            for r in res:
+                r["msg"] = self.lib.zamd_inflate_message(r["status"]).decode()
+            return res, (bytes(d_out.download(out_bytes)) if d_out else None)
+        finally:
+            d_comp.free()
+            if d_out is not None:
+                d_out.free()
+            if d_head is not None:
+                d_head.free()
 
     def debug_dump(self, what: int, chunk: int, max_elems: int, elem_bytes: int) -> bytearray:
         buf = bytearray(max_elems * elem_bytes)

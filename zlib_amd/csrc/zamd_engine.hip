@@ -853,8 +853,10 @@ struct ZeWorkspace {
     uint64_t pdist_len = 0;
 };
 
+struct ZiState;
 struct zamd_engine {
     int device;
+    ZiState *inf;                 /* batch-inflate workspace, created on first use */
     hipStream_t st[2];
     hipEvent_t ev_scan[2];
     ZeWorkspace ws[2];
@@ -865,7 +867,7 @@ struct zamd_engine {
     hipEvent_t ev_call[2];
     struct Tm { hipEvent_t a, b; int which; };
     Tm *tm; int n_tm, cap_tm;
-    double t_ms[8]; int t_n[8];
+    double t_ms[12]; int t_n[12];
     /* last job for debugging */
     ZkJob last_job; bool have_last;
     uint32_t *d_ck_a, *d_ck_c; uint64_t ck_cap;
@@ -937,11 +939,13 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     return ZAMD_OK;
 }
 
+static void zi_free(zamd_engine *e);
 extern "C" void zamd_engine_destroy(zamd_engine *e)
 {
     if (!e) return;
     hipSetDevice(e->device);
     hipDeviceSynchronize();
+    zi_free(e);
     for (int i = 0; i < 2; i++) { ws_free(e->ws[i]); hipStreamDestroy(e->st[i]); hipEventDestroy(e->ev_scan[i]); hipEventDestroy(e->ev_call[i]); }
     for (int i = 0; i < e->cap_tm; i++) { hipEventDestroy(e->tm[i].a); hipEventDestroy(e->tm[i].b); }
     free(e->tm);
@@ -1100,7 +1104,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     uint64_t total = 0; uint32_t err = 0;
     HIPCHK(hipMemcpy(&total, e->d_total, 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&err, e->d_err, 4, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; k++) { e->t_ms[k] = 0; e->t_n[k] = 0; }
+    for (int k = 0; k < 12; k++) { e->t_ms[k] = 0; e->t_n[k] = 0; }
     for (int i = 0; i < e->n_tm; i++) { float ms = 0; if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->t_ms[e->tm[i].which] += ms; e->t_n[e->tm[i].which]++; } }
     { float ms = 0; if (hipEventElapsedTime(&ms, e->ev_call[0], e->ev_call[1]) == hipSuccess) { e->t_ms[6] = ms; e->t_n[6] = 1; } }
     if (total_out) *total_out = total;
@@ -1118,7 +1122,7 @@ extern "C" int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, ui
 
 extern "C" double zamd_last_timing_ms(zamd_engine *e, int which, int *launches)
 {
-    if (!e || which < 0 || which > 7) return 0;
+    if (!e || which < 0 || which > 11) return 0;
     if (launches) *launches = e->t_n[which];
     return e->t_ms[which];
 }
@@ -1210,11 +1214,7 @@ extern "C" int zamd_adler32_dev(zamd_engine *e, uint32_t adler, const void *d_in
 extern "C" int zamd_crc32_dev(zamd_engine *e, uint32_t crc, const void *d_in, uint64_t n, uint32_t *result)
 { return whole_checksum(e, d_in, n, 1, crc, result); }
 
-extern "C" int zamd_inflate_dev(zamd_engine *, const void *, const uint64_t *, uint64_t, uint32_t, void *, uint64_t, int64_t *)
-{
-    fprintf(stderr, "zamd: batch inflate is not implemented yet\n");
-    return ZAMD_STREAM_ERROR;
-}
+#include "zamd_inflate_impl.h"
 
 /* ------------------------------------------------------------------ device-memory helpers */
 extern "C" int zamd_dev_alloc(zamd_engine *e, uint64_t bytes, void **d_ptr)

@@ -1,0 +1,654 @@
+/*
+ * zamd_inflate_impl.h — batch inflate kernels and their host entry points.
+ * Included by zamd_engine.hip (one translation unit, shares zamd_engine).
+ *
+ * Work unit: a SEGMENT of a raw deflate stream — a bit position where a block
+ * starts, the byte where the readable input ends, and where its output goes.
+ * One wavefront decodes one segment (k_inf_decode):
+ *   - the compressed bytes are held 2 x 256 B at a time in two VGPRs (one dword
+ *     per lane) and picked out with v_readlane, so the bit reader makes no
+ *     memory access per symbol;
+ *   - Huffman tables are per-wave LDS images: a 2^10 (literal/length) or 2^8
+ *     (distance) first-level table of u16 {symbol, length}; longer codes fall
+ *     back to the canonical first-code search;
+ *   - decoded symbols are parked one per lane; every 64 symbols the wave scans
+ *     their lengths, stores the literals and copies the matches cooperatively.
+ * Output is first written as 16-bit elements: values >= 256 name a byte of the
+ * 32 KiB of output in front of the segment, which another wave is producing at
+ * the same time.  k_inf_tail_* then resolve the last 32 KiB of every segment in
+ * stream order and k_inf_final resolves everything else in parallel and writes
+ * the bytes.
+ *
+ * Semantics follow inflate.c:605-1252 (block headers :836-895, dynamic tables
+ * :896-1003, codes :1005-1200) and inftrees.c:32-306 (validity rules of code
+ * length sets); error numbers map to the reference's message strings.
+ */
+
+#define ZI_ROOT_L 10
+#define ZI_ROOT_D 8
+#define ZI_ROOT_C 7
+#define ZI_MARK   256u       /* first marker value: byte 0 of the preceding 32 KiB */
+__constant__ uint8_t zi_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   /* inflate.c:608-609 */
+
+enum {
+    ZI_OK_END = 0, ZI_OK_FINAL = 1, ZI_OK_SYNC = 2, ZI_NEED_INPUT = 3,
+    ZI_ERR_BTYPE = 16, ZI_ERR_STORED, ZI_ERR_TOOMANY, ZI_ERR_CLSET, ZI_ERR_REPEAT, ZI_ERR_NOEOB,
+    ZI_ERR_LLSET, ZI_ERR_DSET, ZI_ERR_LCODE, ZI_ERR_DCODE, ZI_ERR_FAR, ZI_ERR_OUTCAP, ZI_ERR_LENGTH
+};
+#define ZI_MODE_SYNCSTOP 1u
+#define ZI_MODE_EXACT    2u
+
+static const char *zi_message(uint32_t status)
+{
+    switch (status) {   /* strings of inflate.c:859, 868, 907, 929, 952/975, 989, 1003, 1012, inffast.c:273/288, 180/190 */
+    case ZI_ERR_BTYPE:   return "invalid block type";
+    case ZI_ERR_STORED:  return "invalid stored block lengths";
+    case ZI_ERR_TOOMANY: return "too many length or distance symbols";
+    case ZI_ERR_CLSET:   return "invalid code lengths set";
+    case ZI_ERR_REPEAT:  return "invalid bit length repeat";
+    case ZI_ERR_NOEOB:   return "invalid code -- missing end-of-block";
+    case ZI_ERR_LLSET:   return "invalid literal/lengths set";
+    case ZI_ERR_DSET:    return "invalid distances set";
+    case ZI_ERR_LCODE:   return "invalid literal/length code";
+    case ZI_ERR_DCODE:   return "invalid distance code";
+    case ZI_ERR_FAR:     return "invalid distance too far back";
+    case ZI_ERR_OUTCAP:  return "output exceeds the space given for the segment";
+    case ZI_ERR_LENGTH:  return "segment did not inflate to the indexed length";
+    case ZI_NEED_INPUT:  return "compressed data ends inside a block";
+    default:             return "";
+    }
+}
+
+/* layout shared with zamd_inflate_seg in zamd.h */
+struct ZiSeg {
+    uint64_t in_bit, in_end_bit, out_off, out_cap;
+    uint32_t win_avail, mode;
+    uint64_t out_len, end_bit;
+    uint32_t status, final_seen;
+};
+
+struct ZiTab {                 /* one canonical code: first-level table + search arrays */
+    uint16_t *lut, *sorted;
+    uint16_t *first, *cnt, *off;   /* indexed by code length 1..15 */
+};
+
+struct ZiLds {
+    uint16_t lut_l[1u << ZI_ROOT_L], lut_d[1u << ZI_ROOT_D], lut_c[1u << ZI_ROOT_C];
+    uint16_t sorted_l[288], sorted_d[32], sorted_c[20];
+    uint16_t meta[3][3][16];
+    uint32_t cntw[16];
+    uint8_t lens[320 + 8];
+    uint8_t cl[20 + 4];
+};
+
+struct ZiBits {
+    const uint32_t *base; uint64_t ndw;   /* readable dwords */
+    uint32_t cur, nxt;                    /* per lane: dword wbase+lane, wbase+64+lane */
+    uint64_t wbase;
+    uint64_t bitpos;
+};
+
+__device__ __forceinline__ uint32_t zi_ldw(const ZiBits &b, uint64_t i) { return i < b.ndw ? b.base[i] : 0u; }
+
+__device__ __forceinline__ void zi_bits_init(ZiBits &b, const uint32_t *base, uint64_t ndw, uint64_t bitpos, uint32_t lane)
+{
+    b.base = base; b.ndw = ndw; b.bitpos = bitpos;
+    b.wbase = (bitpos >> 5) & ~63ull;
+    b.cur = zi_ldw(b, b.wbase + lane);
+    b.nxt = zi_ldw(b, b.wbase + 64 + lane);
+}
+
+/* >= 33 valid bits at the current position (wave-uniform result) */
+__device__ __forceinline__ uint64_t zi_peek(ZiBits &b, uint32_t lane)
+{
+    uint64_t dw = (b.bitpos >> 5) - b.wbase;
+    while (dw >= 64) {
+        b.cur = b.nxt; b.wbase += 64; b.nxt = zi_ldw(b, b.wbase + 64 + lane); dw -= 64;
+        if (dw >= 64) {       /* a jump over more than one window (stored blocks) */
+            b.wbase = (b.bitpos >> 5) & ~63ull;
+            b.cur = zi_ldw(b, b.wbase + lane); b.nxt = zi_ldw(b, b.wbase + 64 + lane);
+            dw = (b.bitpos >> 5) - b.wbase;
+        }
+    }
+    uint32_t d0 = (uint32_t)dw;
+    uint32_t lo = __builtin_amdgcn_readlane(b.cur, d0);
+    uint32_t hi1 = __builtin_amdgcn_readlane(b.cur, (d0 + 1) & 63u);
+    uint32_t hi2 = __builtin_amdgcn_readlane(b.nxt, 0);
+    uint32_t hi = d0 == 63 ? hi2 : hi1;
+    return (((uint64_t)hi << 32) | lo) >> (b.bitpos & 31u);
+}
+
+__device__ __forceinline__ uint32_t zi_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+/* Builds the tables of one code from lens[0..n).  Returns 0 = complete, 1 =
+ * over-subscribed, 2 = incomplete; *maxlen = longest code (0 = no codes).
+ * (Validity rules: inftrees.c:107-138.) */
+__device__ uint32_t zi_build(ZiLds &L, const uint8_t *lens, uint32_t n, uint32_t root, ZiTab T, uint32_t lane, uint32_t *maxlen)
+{
+    if (lane < 16) L.cntw[lane] = 0;
+    __syncthreads();
+    for (uint32_t s = lane; s < n; s += 64) atomicAdd(&L.cntw[lens[s]], 1u);
+    __syncthreads();
+    uint32_t cntv = lane < 16 ? L.cntw[lane] : 0u;      /* lane l: number of codes of length l */
+    int32_t left = 1; uint32_t code = 0, offs = 0, mx = 0, over = 0;
+    for (uint32_t l = 1; l <= 15; l++) {
+        uint32_t c = __builtin_amdgcn_readlane(cntv, l);
+        left = (left << 1) - (int32_t)c;
+        if (left < 0) { over = 1; left = 0; }
+        if (c) mx = l;
+        if (lane == 0) { T.first[l] = (uint16_t)code; T.cnt[l] = (uint16_t)c; T.off[l] = (uint16_t)offs; }
+        code = (code + c) << 1;
+        offs += c;
+    }
+    *maxlen = mx;
+    __syncthreads();
+    if (over) return 1;
+    /* stable placement by (length, symbol): 64 symbols per round */
+    uint32_t runv = 0;                                   /* lane l: codes of length l placed so far */
+    for (uint32_t s0 = 0; s0 < n; s0 += 64) {
+        uint32_t s = s0 + lane;
+        uint32_t myl = s < n ? lens[s] : 0u;
+        uint32_t pos = 0;
+        for (uint32_t l = 1; l <= mx; l++) {
+            uint64_t bal = __ballot(myl == l);
+            if (bal == 0) continue;
+            uint32_t base = __builtin_amdgcn_readlane(runv, l);
+            if (myl == l) pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == l) runv += __popcll(bal);
+        }
+        if (myl) T.sorted[T.off[myl] + pos] = (uint16_t)s;
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < (1u << root); i += 64) {
+        uint32_t rev = __brev(i) >> (32 - root);
+        uint32_t e = 0;
+        uint32_t lim = mx < root ? mx : root;
+        for (uint32_t l = 1; l <= lim; l++) {
+            uint32_t d = (rev >> (root - l)) - T.first[l];
+            if (d < T.cnt[l]) { e = ((uint32_t)T.sorted[T.off[l] + d] << 4) | l; break; }
+        }
+        T.lut[i] = (uint16_t)e;
+    }
+    __syncthreads();
+    return left > 0 ? 2u : 0u;
+}
+
+/* Code longer than the first-level table: canonical search.  Returns symbol |
+ * length << 16, or 0xffffffff when no code matches. */
+__device__ __forceinline__ uint32_t zi_slow(const ZiTab &T, uint32_t bits, uint32_t root)
+{
+    uint32_t rev = __brev(bits) >> 17;                   /* first 15 stream bits, first bit on top */
+    for (uint32_t l = root + 1; l <= 15; l++) {
+        uint32_t d = (rev >> (15 - l)) - zi_uni(T.first[l]);
+        if (d < zi_uni(T.cnt[l])) return zi_uni(T.sorted[zi_uni(T.off[l]) + d]) | (l << 16);
+    }
+    return 0xffffffffu;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16)
+{
+    __shared__ ZiLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t si = blockIdx.x;
+    if (si >= nseg) return;
+    ZiSeg S = segs[si];
+    const uint64_t end_bits = S.in_end_bit;
+    ZiBits B;
+    zi_bits_init(B, (const uint32_t *)comp, (comp_bytes + 3) >> 2, S.in_bit, lane);
+    ZiTab TL{L.lut_l, L.sorted_l, L.meta[0][0], L.meta[0][1], L.meta[0][2]};
+    ZiTab TD{L.lut_d, L.sorted_d, L.meta[1][0], L.meta[1][1], L.meta[1][2]};
+    ZiTab TC{L.lut_c, L.sorted_c, L.meta[2][0], L.meta[2][1], L.meta[2][2]};
+    uint16_t *dst = out16 + S.out_off;
+
+    uint64_t pos = 0;                  /* elements produced so far */
+    uint64_t good_bit = S.in_bit, good_pos = 0;
+    uint32_t status = 0xffffffffu, final_seen = 0;
+    bool fixed_ready = false;
+    uint32_t mysym = 0, k = 0;
+
+    /* flushes the parked symbols; returns false on error (status set) */
+    auto flush = [&]() -> bool {
+        if (k == 0) return true;
+        if (B.bitpos > end_bits) { status = ZI_NEED_INPUT; return false; }   /* some parked symbols came from beyond the input */
+        const bool valid = lane < k;
+        const uint32_t w = mysym;
+        const bool ism = valid && (w >> 31);
+        const uint32_t len = valid ? (ism ? ((w >> 16) & 0xffu) + 3u : 1u) : 0u;
+        uint32_t incl = len;
+        for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if ((int)lane >= d) incl += t; }
+        const uint32_t off = incl - len;
+        const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        /* distance checks (inflate.c:1145-1158) */
+        bool far = ism && ((int64_t)(pos + off) - (int64_t)(w & 0xffffu) < -(int64_t)S.win_avail);
+        if (__ballot(far)) { status = ZI_ERR_FAR; return false; }
+        if (pos + total > S.out_cap) { status = ZI_ERR_OUTCAP; return false; }
+        if (WRITE) {
+            if (valid && !ism) dst[pos + off] = (uint16_t)w;
+            uint64_t mm = __ballot(ism);
+            while (mm) {
+                const uint32_t m = (uint32_t)__builtin_ctzll(mm);
+                mm &= mm - 1;
+                const uint32_t wm = __builtin_amdgcn_readlane(w, m);
+                const uint32_t om = __builtin_amdgcn_readlane(off, m);
+                const uint32_t ml = ((wm >> 16) & 0xffu) + 3u, md = wm & 0xffffu;
+                const int64_t d0 = (int64_t)(pos + om), s0 = d0 - (int64_t)md;
+                if (s0 + (int64_t)ml > (int64_t)pos) __threadfence_block();   /* reads what this batch wrote */
+                for (uint32_t j = lane; j < ml; j += 64) {
+                    const int64_t sj = s0 + (int64_t)(md >= ml ? j : j % md);
+                    uint16_t v;
+                    if (sj < 0) v = (uint16_t)(ZI_MARK + 32768 + sj);
+                    else v = dst[sj];
+                    dst[d0 + j] = v;
+                }
+            }
+            __threadfence_block();
+        }
+        pos += total; k = 0;
+        return true;
+    };
+    /* an error only counts when every bit that led to it lies inside the input */
+    auto fail = [&](uint32_t code, uint32_t ahead) { status = (B.bitpos + ahead > end_bits) ? (uint32_t)ZI_NEED_INPUT : code; };
+
+    while (status == 0xffffffffu) {
+        if (B.bitpos + 3 > end_bits) { status = (B.bitpos == end_bits) ? (uint32_t)ZI_OK_END : (uint32_t)ZI_NEED_INPUT; break; }
+        uint64_t bits = zi_peek(B, lane);
+        const uint32_t last = (uint32_t)bits & 1u, type = ((uint32_t)bits >> 1) & 3u;
+        B.bitpos += 3;
+        bool empty_stored = false;
+        if (type == 0) {
+            B.bitpos = (B.bitpos + 7) & ~7ull;
+            if (B.bitpos + 32 > end_bits) { status = ZI_NEED_INPUT; break; }
+            bits = zi_peek(B, lane);
+            const uint32_t sl = (uint32_t)bits & 0xffffu, nsl = ((uint32_t)bits >> 16) & 0xffffu;
+            if (sl != (nsl ^ 0xffffu)) { fail(ZI_ERR_STORED, 32); break; }
+            B.bitpos += 32;
+            const uint64_t byte0 = B.bitpos >> 3;
+            if ((byte0 + sl) * 8ull > end_bits) { status = ZI_NEED_INPUT; break; }
+            if (pos + sl > S.out_cap) { status = ZI_ERR_OUTCAP; break; }
+            if (WRITE) { for (uint32_t j = lane; j < sl; j += 64) dst[pos + j] = comp[byte0 + j]; __threadfence_block(); }
+            pos += sl;
+            B.bitpos += 8ull * sl;
+            empty_stored = sl == 0;
+        } else if (type == 3) {
+            fail(ZI_ERR_BTYPE, 0); break;
+        } else {
+            if (type == 1) {
+                if (!fixed_ready) {
+                    for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                    if (lane < 32) L.lens[288 + lane] = 5;
+                    __syncthreads();
+                    uint32_t mx;
+                    zi_build(L, L.lens, 288, ZI_ROOT_L, TL, lane, &mx);
+                    zi_build(L, L.lens + 288, 32, ZI_ROOT_D, TD, lane, &mx);
+                    fixed_ready = true;
+                }
+            } else {
+                fixed_ready = false;
+                if (B.bitpos + 14 > end_bits) { status = ZI_NEED_INPUT; break; }
+                const uint32_t nlen = ((uint32_t)bits >> 3 & 31u) + 257u, ndist = ((uint32_t)bits >> 8 & 31u) + 1u,
+                               ncode = ((uint32_t)bits >> 13 & 15u) + 4u;
+                B.bitpos += 14;
+                if (nlen > 286 || ndist > 30) { fail(ZI_ERR_TOOMANY, 0); break; }
+                if (lane < 19) L.cl[lane] = 0;
+                __syncthreads();
+                for (uint32_t i = 0; i < ncode;) {       /* 3-bit lengths, 11 per peek */
+                    bits = zi_peek(B, lane);
+                    uint32_t take = ncode - i < 11 ? ncode - i : 11;
+                    if (lane < take) L.cl[zi_order[i + lane]] = (uint8_t)((bits >> (3 * lane)) & 7u);
+                    B.bitpos += 3 * take; i += take;
+                }
+                __syncthreads();
+                if (B.bitpos > end_bits) { status = ZI_NEED_INPUT; break; }
+                uint32_t mx;
+                uint32_t r = zi_build(L, L.cl, 19, ZI_ROOT_C, TC, lane, &mx);
+                if (r != 0 && mx != 0) { fail(ZI_ERR_CLSET, 0); break; }      /* incomplete sets are invalid for this code */
+                const uint32_t total = nlen + ndist;
+                uint32_t idx = 0;
+                bool bad = false;
+                while (idx < total) {
+                    bits = zi_peek(B, lane);
+                    uint32_t e = zi_uni(L.lut_c[(uint32_t)bits & 127u]);
+                    uint32_t l = e & 15u, sym = e >> 4;
+                    if (l == 0) { l = 1; sym = 0; }                          /* empty code: inftrees.c:118-125 */
+                    bits >>= l; B.bitpos += l;
+                    if (sym < 16) {
+                        if (lane == 0) L.lens[idx] = (uint8_t)sym;
+                        idx++;
+                    } else {
+                        uint32_t rep, val = 0;
+                        if (sym == 16) {
+                            rep = 3 + ((uint32_t)bits & 3u); B.bitpos += 2;
+                            if (idx == 0) { fail(ZI_ERR_REPEAT, 0); bad = true; break; }
+                            __syncthreads();
+                            val = zi_uni(L.lens[idx - 1]);
+                        } else if (sym == 17) { rep = 3 + ((uint32_t)bits & 7u); B.bitpos += 3; }
+                        else { rep = 11 + ((uint32_t)bits & 127u); B.bitpos += 7; }
+                        if (idx + rep > total) { fail(ZI_ERR_REPEAT, 0); bad = true; break; }
+                        for (uint32_t j = lane; j < rep; j += 64) L.lens[idx + j] = (uint8_t)val;
+                        idx += rep;
+                    }
+                    if (B.bitpos > end_bits + 64) { status = ZI_NEED_INPUT; bad = true; break; }
+                }
+                if (bad) break;
+                __syncthreads();
+                if (B.bitpos > end_bits) { status = ZI_NEED_INPUT; break; }
+                if (zi_uni(L.lens[256]) == 0) { fail(ZI_ERR_NOEOB, 0); break; }
+                /* distance lengths follow the literal/length lengths; move them to a fixed place */
+                uint8_t dl = lane < ndist ? L.lens[nlen + lane] : 0;
+                __syncthreads();
+                if (lane < 32) L.lens[288 + lane] = dl;
+                __syncthreads();
+                r = zi_build(L, L.lens, nlen, ZI_ROOT_L, TL, lane, &mx);
+                if (r == 1 || (r == 2 && mx != 1)) { fail(ZI_ERR_LLSET, 0); break; }
+                r = zi_build(L, L.lens + 288, ndist, ZI_ROOT_D, TD, lane, &mx);
+                if (r == 1 || (r == 2 && mx > 1)) { fail(ZI_ERR_DSET, 0); break; }
+            }
+            /* ---- symbols of the block */
+            bool bad = false;
+            for (;;) {
+                bits = zi_peek(B, lane);
+                uint32_t e = zi_uni(L.lut_l[(uint32_t)bits & ((1u << ZI_ROOT_L) - 1u)]);
+                uint32_t l = e & 15u, sym = e >> 4;
+                if (l == 0) {
+                    uint32_t r = zi_slow(TL, (uint32_t)bits, ZI_ROOT_L);
+                    if (r == 0xffffffffu) { fail(ZI_ERR_LCODE, 1); bad = true; break; }
+                    sym = r & 0xffffu; l = r >> 16;
+                }
+                B.bitpos += l;
+                uint32_t word;
+                if (sym < 256) word = sym;
+                else if (sym == 256) break;
+                else {
+                    if (sym > 285) { fail(ZI_ERR_LCODE, 0); bad = true; break; }
+                    bits >>= l;
+                    const uint32_t lc = sym - 257u, lx = zc_len_extra(lc);
+                    const uint32_t mlen = zc_len_base(lc) + ((uint32_t)bits & ((1u << lx) - 1u));   /* length - 3 */
+                    B.bitpos += lx;
+                    bits = zi_peek(B, lane);
+                    e = zi_uni(L.lut_d[(uint32_t)bits & ((1u << ZI_ROOT_D) - 1u)]);
+                    l = e & 15u;
+                    uint32_t ds = e >> 4;
+                    if (l == 0) {
+                        uint32_t r = zi_slow(TD, (uint32_t)bits, ZI_ROOT_D);
+                        if (r == 0xffffffffu) { fail(ZI_ERR_DCODE, 1); bad = true; break; }
+                        ds = r & 0xffffu; l = r >> 16;
+                    }
+                    if (ds >= 30) { B.bitpos += l; fail(ZI_ERR_DCODE, 0); bad = true; break; }
+                    bits >>= l;
+                    const uint32_t dx = zc_dist_extra(ds);
+                    const uint32_t dist = 1u + zc_dist_base(ds) + ((uint32_t)bits & ((1u << dx) - 1u));
+                    B.bitpos += l + dx;
+                    word = 0x80000000u | (mlen << 16) | dist;
+                }
+                mysym = lane == k ? word : mysym;
+                if (++k == 64) { if (!flush()) { bad = true; break; } }
+            }
+            if (bad) break;
+        }
+        if (!flush()) break;
+        if (B.bitpos > end_bits) { status = ZI_NEED_INPUT; break; }
+        good_bit = B.bitpos; good_pos = pos;
+        if (last) { final_seen = 1; status = ZI_OK_FINAL; break; }
+        if (empty_stored && (S.mode & ZI_MODE_SYNCSTOP)) { status = ZI_OK_SYNC; break; }
+    }
+    if ((S.mode & ZI_MODE_EXACT) && status < 3 && good_pos != S.out_cap) status = ZI_ERR_LENGTH;
+    if (lane == 0) {
+        segs[si].out_len = good_pos; segs[si].end_bit = good_bit; segs[si].status = status; segs[si].final_seen = final_seen;
+    }
+}
+
+/* Segment table of a chunk-indexed stream: chunk i = comp[off[i], off[i+1]) ->
+ * out[i * chunk_size ...). */
+__global__ void k_inf_setup(const uint64_t *chunk_off, uint64_t nchunks, uint32_t chunk_size, uint64_t n_out, uint32_t head_avail, ZiSeg *segs)
+{
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchunks) return;
+    ZiSeg s;
+    s.in_bit = chunk_off[i] * 8ull; s.in_end_bit = chunk_off[i + 1] * 8ull;
+    s.out_off = i * (uint64_t)chunk_size;
+    uint64_t rest = n_out > s.out_off ? n_out - s.out_off : 0;
+    s.out_cap = rest < chunk_size ? rest : chunk_size;
+    uint64_t before = s.out_off + head_avail;
+    s.win_avail = (uint32_t)(before < 32768 ? before : 32768);
+    s.mode = ZI_MODE_EXACT;
+    s.out_len = 0; s.end_bit = 0; s.status = 0xffffffffu; s.final_seen = 0;
+    segs[i] = s;
+}
+
+/* result[0] = index of the first segment whose status is not a success, or ~0 */
+__global__ __launch_bounds__(1024) void k_inf_status(const ZiSeg *segs, uint64_t nseg, unsigned long long *result)
+{
+    unsigned long long best = ~0ull;
+    for (uint64_t i = threadIdx.x; i < nseg; i += 1024) if (segs[i].status >= 3 && i < best) best = i;
+    if (best != ~0ull) atomicMin(result, best);
+}
+
+__device__ __forceinline__ uint8_t zi_window_byte(const ZiSeg &S, uint32_t marker, const uint8_t *out8, const uint8_t *head)
+{
+    int64_t q = (int64_t)S.out_off - 32768 + (int64_t)(marker - ZI_MARK);
+    if (q >= 0) return __hip_atomic_load(out8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return head[32768 + q];
+}
+
+/* Last 32 KiB of every segment: plain bytes are written out, markers counted. */
+__global__ __launch_bounds__(1024) void k_inf_tail_pre(const ZiSeg *segs, const uint16_t *out16, uint8_t *out8, uint32_t *marks)
+{
+    const uint32_t si = blockIdx.x >> 5, part = blockIdx.x & 31u;
+    const ZiSeg S = segs[si];
+    const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
+    const uint64_t e = (uint64_t)part * 1024 + threadIdx.x;
+    uint32_t mk = 0;
+    if (e < tl) {
+        const uint64_t p = S.out_off + S.out_len - tl + e;
+        const uint16_t v = out16[p];
+        if (v < ZI_MARK) out8[p] = (uint8_t)v; else mk = 1;
+    }
+    uint64_t b = __ballot(mk);
+    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&marks[si], (uint32_t)__popcll(b));
+}
+
+/* Markers inside those tails, in stream order: each needs the (already resolved)
+ * tail in front of it. */
+__global__ __launch_bounds__(1024) void k_inf_tail_serial(const ZiSeg *segs, uint64_t nseg, const uint16_t *out16, uint8_t *out8,
+                                                          const uint32_t *marks, const uint8_t *head)
+{
+    for (uint64_t si = 0; si < nseg; si++) {
+        if (marks[si] == 0) continue;
+        const ZiSeg S = segs[si];
+        const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
+        for (uint64_t e = threadIdx.x; e < tl; e += 1024) {
+            const uint64_t p = S.out_off + S.out_len - tl + e;
+            const uint16_t v = out16[p];
+            if (v >= ZI_MARK) out8[p] = zi_window_byte(S, v, out8, head);
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+/* Everything in front of the tails: 8 elements per thread. */
+__global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t nseg, uint32_t chunk_size, const uint16_t *out16,
+                                                   uint8_t *out8, const uint8_t *head, uint64_t total)
+{
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p0 >= total) return;
+    uint64_t si;
+    if (chunk_size) si = p0 / chunk_size;
+    else {
+        uint64_t lo = 0, hi = nseg - 1;
+        while (lo < hi) { uint64_t mid = (lo + hi + 1) >> 1; if (segs[mid].out_off <= p0) lo = mid; else hi = mid - 1; }
+        si = lo;
+    }
+    ZiSeg S = segs[si];
+    uint64_t seg_end = S.out_off + S.out_len;
+    uint64_t tail0 = seg_end - (S.out_len < 32768 ? S.out_len : 32768);
+    if (p0 + 8 <= tail0) {
+        const uint4 q = *(const uint4 *)(out16 + p0);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        uint32_t b[2] = {0, 0};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t v = (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+            if (v >= ZI_MARK) v = zi_window_byte(S, v, out8, head);
+            b[i >> 2] |= v << ((i & 3) * 8);
+        }
+        *(uint2 *)(out8 + p0) = make_uint2(b[0], b[1]);
+        return;
+    }
+    for (int i = 0; i < 8; i++) {
+        const uint64_t p = p0 + i;
+        if (p >= total) break;
+        while (p >= seg_end && si + 1 < nseg) {
+            si++; S = segs[si]; seg_end = S.out_off + S.out_len; tail0 = seg_end - (S.out_len < 32768 ? S.out_len : 32768);
+        }
+        if (p < S.out_off || p >= tail0) continue;      /* tails are already written */
+        uint32_t v = out16[p];
+        if (v >= ZI_MARK) v = zi_window_byte(S, v, out8, head);
+        out8[p] = (uint8_t)v;
+    }
+}
+
+/* ------------------------------------------------------------------ host side */
+struct ZiState {
+    ZiSeg *d_segs = nullptr; uint64_t seg_cap = 0;
+    uint16_t *d_stage = nullptr; uint64_t stage_cap = 0;     /* elements */
+    uint32_t *d_marks = nullptr; uint64_t marks_cap = 0;
+    unsigned long long *d_res = nullptr;
+    uint32_t last_status = 0; int64_t last_seg = -1;
+};
+
+static void zi_free(zamd_engine *e)
+{
+    ZiState *z = e->inf;
+    if (!z) return;
+    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_res);
+    delete z; e->inf = nullptr;
+}
+
+static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems)
+{
+    if (!e->inf) { e->inf = new (std::nothrow) ZiState(); if (!e->inf) return ZAMD_MEM_ERROR; }
+    ZiState *z = e->inf;
+    if (!z->d_res) HIPCHK(hipMalloc((void **)&z->d_res, 16));
+    if (z->seg_cap < nseg) {
+        hipFree(z->d_segs); hipFree(z->d_marks); z->d_segs = nullptr; z->d_marks = nullptr; z->seg_cap = 0;
+        uint64_t want = nseg + nseg / 4 + 16;
+        if (hipMalloc((void **)&z->d_segs, want * sizeof(ZiSeg)) != hipSuccess) return ZAMD_MEM_ERROR;
+        if (hipMalloc((void **)&z->d_marks, want * 4) != hipSuccess) return ZAMD_MEM_ERROR;
+        z->seg_cap = want;
+    }
+    if (z->stage_cap < stage_elems) {
+        hipFree(z->d_stage); z->d_stage = nullptr; z->stage_cap = 0;
+        uint64_t want = stage_elems + 64;
+        if (hipMalloc((void **)&z->d_stage, want * 2) != hipSuccess) return ZAMD_MEM_ERROR;
+        z->stage_cap = want;
+    }
+    return ZAMD_OK;
+}
+
+/* decode (+ resolve when d_out != NULL) the segments already in z->d_segs */
+static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint64_t nseg, uint32_t chunk_size,
+                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg)
+{
+    ZiState *z = e->inf;
+    hipStream_t s = e->st[0];
+    int slot;
+    e->n_tm = 0;
+    HIPCHK(hipMemsetAsync(z->d_res, 0xff, 8, s));
+    tm_begin(e, s, 7, &slot);
+    if (d_out) hipLaunchKernelGGL((k_inf_decode<true>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, z->d_stage);
+    else hipLaunchKernelGGL((k_inf_decode<false>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, (uint16_t *)nullptr);
+    tm_end(e, s, slot);
+    hipLaunchKernelGGL(k_inf_status, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, z->d_res);
+    unsigned long long bad = ~0ull;
+    HIPCHK(hipMemcpyAsync(&bad, z->d_res, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    z->last_status = 0; z->last_seg = -1;
+    int rc = ZAMD_OK;
+    if (bad != ~0ull) {
+        ZiSeg hs;
+        HIPCHK(hipMemcpy(&hs, z->d_segs + bad, sizeof hs, hipMemcpyDeviceToHost));
+        z->last_status = hs.status; z->last_seg = (int64_t)bad;
+        if (bad_seg) *bad_seg = (int64_t)bad;
+        rc = ZAMD_DATA_ERROR;
+    }
+    if (d_out && rc == ZAMD_OK && out_bytes) {
+        tm_begin(e, s, 8, &slot);
+        HIPCHK(hipMemsetAsync(z->d_marks, 0, nseg * 4, s));
+        hipLaunchKernelGGL(k_inf_tail_pre, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (uint8_t *)d_out, z->d_marks);
+        hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, z->d_stage, (uint8_t *)d_out, z->d_marks, (const uint8_t *)d_head);
+        uint64_t groups = (out_bytes + 2047) / 2048;
+        hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, chunk_size, z->d_stage, (uint8_t *)d_out, (const uint8_t *)d_head, out_bytes);
+        tm_end(e, s, slot);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    for (int k2 = 0; k2 < 12; k2++) { e->t_ms[k2] = 0; e->t_n[k2] = 0; }
+    for (int i = 0; i < e->n_tm; i++) { float ms = 0; if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->t_ms[e->tm[i].which] += ms; e->t_n[e->tm[i].which]++; } }
+    return rc;
+}
+
+extern "C" int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                                      uint32_t chunk_size, const void *d_head_window, void *d_out, uint64_t n_out, int64_t *bad_chunk)
+{
+    if (!e || !d_comp || !d_chunk_off || !d_out || chunk_size == 0 || (chunk_size & 7u)) return ZAMD_STREAM_ERROR;
+    if (((uintptr_t)d_comp & 3u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
+    if (n_chunks == 0 || n_chunks > 0x7fffffffull / 32) return ZAMD_STREAM_ERROR;
+    if ((n_out + chunk_size - 1) / chunk_size > n_chunks) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = zi_ensure(e, n_chunks, n_chunks * (uint64_t)chunk_size);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_inf_setup, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, e->st[0], d_chunk_off, n_chunks, chunk_size, n_out,
+                       d_head_window ? 32768u : 0u, e->inf->d_segs);
+    return zi_run(e, d_comp, comp_bytes, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk);
+}
+
+extern "C" int zamd_inflate_dev(zamd_engine *e, const void *d_comp, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                                uint32_t chunk_size, void *d_out, uint64_t n_out, int64_t *bad_chunk)
+{
+    if (!e || !d_chunk_off || n_chunks == 0) return ZAMD_STREAM_ERROR;
+    uint64_t comp_bytes = 0;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipMemcpy(&comp_bytes, d_chunk_off + n_chunks, 8, hipMemcpyDeviceToHost));
+    return zamd_inflate_shard_dev(e, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size, nullptr, d_out, n_out, bad_chunk);
+}
+
+extern "C" int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, zamd_inflate_seg *segs, uint64_t nseg,
+                                         const void *d_head_window, void *d_out, uint64_t out_bytes)
+{
+    static_assert(sizeof(zamd_inflate_seg) == sizeof(ZiSeg), "segment layouts must agree");
+    if (!e || !d_comp || !segs || nseg == 0 || nseg > 0x7fffffffull / 32) return ZAMD_STREAM_ERROR;
+    if (((uintptr_t)d_comp & 3u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
+    uint64_t need = 0;
+    for (uint64_t i = 0; i < nseg; i++) {
+        if (segs[i].in_end_bit > comp_bytes * 8 || segs[i].in_bit > segs[i].in_end_bit || segs[i].win_avail > 32768) return ZAMD_STREAM_ERROR;
+        if (d_out) {
+            if (segs[i].out_off + segs[i].out_cap > out_bytes) return ZAMD_STREAM_ERROR;
+            if (i && segs[i].out_off < segs[i - 1].out_off + segs[i - 1].out_cap) return ZAMD_STREAM_ERROR;
+            if (segs[i].win_avail > segs[i].out_off && !d_head_window) return ZAMD_STREAM_ERROR;
+            need = segs[i].out_off + segs[i].out_cap;
+        }
+        segs[i].status = 0xffffffffu;
+    }
+    HIPCHK(hipSetDevice(e->device));
+    int rc = zi_ensure(e, nseg, need);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(e->inf->d_segs, segs, nseg * sizeof(ZiSeg), hipMemcpyHostToDevice));
+    /* every segment is reported, so a failing one is not an error of the call */
+    int64_t bad = -1;
+    rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad);
+    if (rc != ZAMD_OK && rc != ZAMD_DATA_ERROR) return rc;
+    HIPCHK(hipMemcpy(segs, e->inf->d_segs, nseg * sizeof(ZiSeg), hipMemcpyDeviceToHost));
+    return ZAMD_OK;
+}
+
+extern "C" const char *zamd_inflate_message(uint32_t status) { return zi_message(status); }
+
+extern "C" int zamd_inflate_last_error(zamd_engine *e, int64_t *segment, uint32_t *status)
+{
+    if (!e || !e->inf) return ZAMD_STREAM_ERROR;
+    if (segment) *segment = e->inf->last_seg;
+    if (status) *status = e->inf->last_status;
+    return ZAMD_OK;
+}
