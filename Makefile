@@ -10,7 +10,7 @@ zlib_amd/libzamd.so: $(SRCS) $(HDRS)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -o $@ $(SRCS)
 
 zlib_amd/libzamd_z.so: zlib_amd/csrc/zamd_zlib.cpp include/zamd_zlib.h include/zamd.h zlib_amd/libzamd.so
-	g++ -O2 -std=c++17 -fPIC -shared -pthread -o $@ zlib_amd/csrc/zamd_zlib.cpp -Lzlib_amd -lzamd -Wl,-rpath,'$$ORIGIN'
+	g++ -O2 -std=c++17 -fPIC -shared -pthread -o $@ zlib_amd/csrc/zamd_zlib.cpp -Lzlib_amd -lzamd -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN'
 
 oracle:
 	$(MAKE) -C oracle

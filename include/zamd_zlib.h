@@ -121,6 +121,16 @@ int inflate(z_streamp strm, int flush);                                         
 int inflateEnd(z_streamp strm);                                                                     /* :1254 */
 int inflateReset(z_streamp strm);                                                                   /* :129 */
 int inflateReset2(z_streamp strm, int windowBits);                                                  /* :141 */
+int inflateResetKeep(z_streamp strm);                                                               /* :104 */
+int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength);                 /* :1291 */
+int inflateGetDictionary(z_streamp strm, Bytef *dictionary, uInt *dictLength);                      /* :1268 */
+int inflateGetHeader(z_streamp strm, gz_headerp head);                                              /* :1326 */
+int inflateSync(z_streamp strm);                                                                    /* :1377 */
+int inflateSyncPoint(z_streamp strm);                                                               /* :1428 */
+int inflateCopy(z_streamp dest, z_streamp source);                                                  /* :1438 */
+int inflateUndermine(z_streamp strm, int subvert);                                                  /* :1485 */
+long inflateMark(z_streamp strm);                                                                   /* :1502 */
+int inflatePrime(z_streamp strm, int bits, int value);            /* :230; not supported: Z_STREAM_ERROR */
 
 /* one-shot utilities: compress.c:22-80, uncompr.c:24-59 */
 int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen);

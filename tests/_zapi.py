@@ -1,0 +1,194 @@
+"""ctypes view of zlib_amd/libzamd_z.so — the zlib 1.2.8 stream API of include/zamd_zlib.h —
+written the way a ctypes-based zlib binding declares it."""
+import ctypes as C
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "zlib_amd", "libzamd_z.so")
+
+Z_NO_FLUSH, Z_PARTIAL_FLUSH, Z_SYNC_FLUSH, Z_FULL_FLUSH, Z_FINISH, Z_BLOCK = 0, 1, 2, 3, 4, 5
+Z_OK, Z_STREAM_END, Z_NEED_DICT = 0, 1, 2
+Z_STREAM_ERROR, Z_DATA_ERROR, Z_MEM_ERROR, Z_BUF_ERROR, Z_VERSION_ERROR = -2, -3, -4, -5, -6
+
+ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint, C.c_uint)
+FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class ZStream(C.Structure):        # zlib.h:85-104
+    _fields_ = [("next_in", C.c_void_p), ("avail_in", C.c_uint), ("total_in", C.c_ulong),
+                ("next_out", C.c_void_p), ("avail_out", C.c_uint), ("total_out", C.c_ulong),
+                ("msg", C.c_char_p), ("state", C.c_void_p),
+                ("zalloc", C.c_void_p), ("zfree", C.c_void_p), ("opaque", C.c_void_p),
+                ("data_type", C.c_int), ("adler", C.c_ulong), ("reserved", C.c_ulong)]
+
+
+class GzHeader(C.Structure):       # zlib.h:109-129
+    _fields_ = [("text", C.c_int), ("time", C.c_ulong), ("xflags", C.c_int), ("os", C.c_int),
+                ("extra", C.c_void_p), ("extra_len", C.c_uint), ("extra_max", C.c_uint),
+                ("name", C.c_void_p), ("name_max", C.c_uint), ("comment", C.c_void_p), ("comm_max", C.c_uint),
+                ("hcrc", C.c_int), ("done", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = C.CDLL(LIB)
+        P = C.POINTER(ZStream)
+        l.zlibVersion.restype = C.c_char_p
+        l.zlibCompileFlags.restype = C.c_ulong
+        l.zError.argtypes = [C.c_int]; l.zError.restype = C.c_char_p
+        l.deflateInit_.argtypes = [P, C.c_int, C.c_char_p, C.c_int]
+        l.deflateInit2_.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        l.inflateInit_.argtypes = [P, C.c_char_p, C.c_int]
+        l.inflateInit2_.argtypes = [P, C.c_int, C.c_char_p, C.c_int]
+        for name in ("deflate", "inflate"):
+            getattr(l, name).argtypes = [P, C.c_int]
+        for name in ("deflateEnd", "deflateReset", "deflateResetKeep", "inflateEnd", "inflateReset", "inflateResetKeep",
+                     "inflateSync", "inflateSyncPoint"):
+            getattr(l, name).argtypes = [P]
+        l.inflateReset2.argtypes = [P, C.c_int]
+        l.deflateParams.argtypes = [P, C.c_int, C.c_int]
+        l.deflateBound.argtypes = [P, C.c_ulong]; l.deflateBound.restype = C.c_ulong
+        l.deflatePending.argtypes = [P, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+        l.deflateSetHeader.argtypes = [P, C.POINTER(GzHeader)]
+        l.inflateGetHeader.argtypes = [P, C.POINTER(GzHeader)]
+        l.deflateCopy.argtypes = [P, P]; l.inflateCopy.argtypes = [P, P]
+        l.deflateSetDictionary.argtypes = [P, C.c_char_p, C.c_uint]
+        l.inflateSetDictionary.argtypes = [P, C.c_char_p, C.c_uint]
+        l.inflateGetDictionary.argtypes = [P, C.c_void_p, C.POINTER(C.c_uint)]
+        l.deflateTune.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.deflatePrime.argtypes = [P, C.c_int, C.c_int]; l.inflatePrime.argtypes = [P, C.c_int, C.c_int]
+        l.inflateUndermine.argtypes = [P, C.c_int]
+        l.inflateMark.argtypes = [P]; l.inflateMark.restype = C.c_long
+        l.compress.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_char_p, C.c_ulong]
+        l.compress2.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_char_p, C.c_ulong, C.c_int]
+        l.uncompress.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_char_p, C.c_ulong]
+        l.compressBound.argtypes = [C.c_ulong]; l.compressBound.restype = C.c_ulong
+        for name in ("adler32", "crc32"):
+            getattr(l, name).argtypes = [C.c_ulong, C.c_char_p, C.c_uint]; getattr(l, name).restype = C.c_ulong
+        for name in ("adler32_combine", "crc32_combine", "adler32_combine64", "crc32_combine64"):
+            getattr(l, name).argtypes = [C.c_ulong, C.c_ulong, C.c_long]; getattr(l, name).restype = C.c_ulong
+        l.get_crc_table.restype = C.POINTER(C.c_uint)
+        _lib = l
+    return _lib
+
+
+VERSION = b"1.2.8"
+SZ = C.sizeof(ZStream)
+
+
+def compress2(data, level=-1, cap=None):
+    l = lib()
+    cap = l.compressBound(len(data)) if cap is None else cap
+    buf = C.create_string_buffer(max(cap, 1))
+    n = C.c_ulong(cap)
+    rc = l.compress2(buf, C.byref(n), bytes(data), len(data), level)
+    return rc, buf.raw[:n.value] if rc == 0 else b""
+
+
+def uncompress(comp, cap):
+    l = lib()
+    buf = C.create_string_buffer(max(cap, 1))
+    n = C.c_ulong(cap)
+    rc = l.uncompress(buf, C.byref(n), bytes(comp), len(comp))
+    return rc, buf.raw[:n.value] if rc == 0 else b""
+
+
+def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out_step=65536, flushes=None, header=None):
+    """Feeds `data` through deflate() in in_step slices with out_step output space per call.
+    flushes: {offset: flush} applied when the input cursor reaches offset.  Returns (rc_list_tail, bytes, strm)."""
+    l = lib()
+    s = ZStream()
+    rc = l.deflateInit2_(C.byref(s), level, 8, wbits, mem, strategy, VERSION, SZ)
+    assert rc == 0, rc
+    if header is not None:
+        assert l.deflateSetHeader(C.byref(s), C.byref(header)) == 0
+    src = C.create_string_buffer(bytes(data), max(len(data), 1))
+    out = bytearray()
+    obuf = C.create_string_buffer(out_step)
+    pos, n = 0, len(data)
+    in_step = in_step or max(n, 1)
+    cuts = sorted((flushes or {}).items())
+    while True:
+        nxt = min(n, pos + in_step)
+        fl = Z_FINISH if nxt == n else Z_NO_FLUSH
+        for off, f in cuts:
+            if pos < off <= nxt:
+                nxt, fl = off, (f if off < n or f == Z_FINISH else f)
+                break
+        s.next_in = C.addressof(src) + pos
+        s.avail_in = nxt - pos
+        while True:
+            s.next_out = C.addressof(obuf)
+            s.avail_out = out_step
+            rc = l.deflate(C.byref(s), fl)
+            assert rc in (Z_OK, Z_STREAM_END, Z_BUF_ERROR), rc
+            out += obuf.raw[:out_step - s.avail_out]
+            if rc == Z_STREAM_END or (s.avail_out != 0 and s.avail_in == 0):
+                break
+        pos = nxt
+        if rc == Z_STREAM_END:
+            break
+        if pos == n and fl != Z_FINISH:
+            cuts = [(n, Z_FINISH)]
+            in_step = 1
+            # one more round with Z_FINISH and no input
+            s.next_in = C.addressof(src) + n
+            s.avail_in = 0
+            while True:
+                s.next_out = C.addressof(obuf); s.avail_out = out_step
+                rc = l.deflate(C.byref(s), Z_FINISH)
+                out += obuf.raw[:out_step - s.avail_out]
+                if rc == Z_STREAM_END:
+                    break
+                assert rc == Z_OK, rc
+            break
+    totals = (s.total_in, s.total_out, s.adler)
+    assert l.deflateEnd(C.byref(s)) == 0
+    return bytes(out), totals
+
+
+def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUSH, header=None, dictionary=None):
+    """Feeds `comp` through inflate().  Returns (rc, bytes, msg, unused_input, totals)."""
+    l = lib()
+    s = ZStream()
+    rc = l.inflateInit2_(C.byref(s), wbits, VERSION, SZ)
+    assert rc == 0, rc
+    if header is not None:
+        assert l.inflateGetHeader(C.byref(s), C.byref(header)) == 0
+    src = C.create_string_buffer(bytes(comp), max(len(comp), 1))
+    obuf = C.create_string_buffer(out_step)
+    out = bytearray()
+    pos, n = 0, len(comp)
+    in_step = in_step or max(n, 1)
+    rc = Z_OK
+    idle = 0
+    while True:
+        nxt = min(n, pos + in_step)
+        s.next_in = C.addressof(src) + pos
+        s.avail_in = nxt - pos
+        while True:
+            s.next_out = C.addressof(obuf)
+            s.avail_out = out_step
+            rc = l.inflate(C.byref(s), flush)
+            if rc == Z_NEED_DICT and dictionary is not None:
+                assert l.inflateSetDictionary(C.byref(s), dictionary, len(dictionary)) == 0
+                continue
+            got = out_step - s.avail_out
+            out += obuf.raw[:got]
+            if rc not in (Z_OK, Z_BUF_ERROR) or (s.avail_out != 0 and s.avail_in == 0) or (rc == Z_BUF_ERROR and got == 0):
+                break
+        pos = nxt - s.avail_in
+        if rc not in (Z_OK, Z_BUF_ERROR):
+            break
+        if nxt == n:
+            idle += 1
+            if idle > 2:
+                break
+    msg = s.msg.decode() if s.msg else None
+    totals = (s.total_in, s.total_out, s.adler)
+    assert l.inflateEnd(C.byref(s)) == 0
+    return rc, bytes(out), msg, n - pos, totals

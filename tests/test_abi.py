@@ -55,3 +55,58 @@ def test_no_cpu_fallback_without_a_device():
         pytest.skip("a GPU is present")
     with pytest.raises(zlib_amd.ZamdError):
         zlib_amd.Engine(0)
+
+
+def _zlib_api_symbols():
+    text = open(os.path.join(ROOT, "include", "zamd_zlib.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("#") and "typedef" not in l)
+    names = set(m.group(1) for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", text))
+    return sorted(n for n in names if n[0].islower() and n not in ("sizeof",))
+
+
+def test_zlib_api_library_exports_every_declared_function():
+    import _zapi as Z
+    lib = Z.lib()
+    names = _zlib_api_symbols()
+    assert len(names) >= 44, names
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/zamd_zlib.h but not exported by libzamd_z.so"
+
+
+def test_zlib_api_host_logic_without_compute():
+    """Argument checking of the stream API (deflate.c:233-275, inflate.c:189-192, zutil.c:30-40, 136)."""
+    import ctypes as C
+    import _zapi as Z
+    lib = Z.lib()
+    assert lib.zlibVersion() == b"1.2.8"
+    assert lib.zlibCompileFlags() == 0xa9
+    assert lib.zError(-3) == b"data error" and lib.zError(2) == b"need dictionary" and lib.zError(0) == b""
+    assert C.sizeof(Z.ZStream) == 112
+    s = Z.ZStream()
+    assert lib.deflateInit_(C.byref(s), 6, b"2.0", Z.SZ) == Z.Z_VERSION_ERROR
+    assert lib.deflateInit_(C.byref(s), 6, Z.VERSION, Z.SZ - 8) == Z.Z_VERSION_ERROR
+    assert lib.inflateInit_(C.byref(s), None, Z.SZ) == Z.Z_VERSION_ERROR
+    assert lib.deflateInit_(None, 6, Z.VERSION, Z.SZ) == Z.Z_STREAM_ERROR
+    for bad in ((10, 8, 15, 8, 0), (6, 7, 15, 8, 0), (6, 8, 16 + 16, 8, 0), (6, 8, 7, 8, 0), (6, 8, 15, 0, 0), (6, 8, 15, 10, 0), (6, 8, 15, 8, 5)):
+        assert lib.deflateInit2_(C.byref(s), *bad, Z.VERSION, Z.SZ) == Z.Z_STREAM_ERROR, bad
+    assert lib.inflateInit2_(C.byref(s), 7, Z.VERSION, Z.SZ) == Z.Z_STREAM_ERROR
+    # a stream can be set up and torn down without touching the GPU
+    assert lib.deflateInit2_(C.byref(s), -1, 8, 31, 9, 1, Z.VERSION, Z.SZ) == Z.Z_OK
+    assert s.zalloc and s.zfree and s.adler == 0 and s.total_in == 0
+    assert lib.deflate(C.byref(s), 9) == Z.Z_STREAM_ERROR            # bad flush value
+    assert lib.deflate(C.byref(s), 0) == Z.Z_STREAM_ERROR            # next_out == NULL
+    assert lib.deflateSetDictionary(C.byref(s), b"abc", 3) == Z.Z_STREAM_ERROR
+    assert lib.deflateEnd(C.byref(s)) == Z.Z_OK and not s.state
+    assert lib.deflateEnd(C.byref(s)) == Z.Z_STREAM_ERROR
+    assert lib.deflateInit2_(C.byref(s), 6, 8, -15, 8, 0, Z.VERSION, Z.SZ) == Z.Z_OK
+    assert lib.deflateEnd(C.byref(s)) == Z.Z_DATA_ERROR              # raw streams start BUSY (deflate.c:413, 1006)
+    assert lib.inflateInit2_(C.byref(s), 47, Z.VERSION, Z.SZ) == Z.Z_OK
+    assert lib.inflate(C.byref(s), 0) == Z.Z_STREAM_ERROR            # next_out == NULL
+    assert lib.inflateUndermine(C.byref(s), 1) == Z.Z_DATA_ERROR
+    assert lib.inflateMark(C.byref(s)) == -65536
+    assert lib.deflate(C.byref(s), 0) == Z.Z_STREAM_ERROR            # an inflate state is not a deflate state
+    assert lib.inflateEnd(C.byref(s)) == Z.Z_OK
+    assert lib.compressBound(1 << 20) >= (1 << 20) + (1 << 8) + (1 << 6) + 13
+    tab = lib.get_crc_table()
+    assert tab[1] == 0x77073096 and tab[255] == 0x2d02ef8d

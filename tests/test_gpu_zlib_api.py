@@ -1,0 +1,199 @@
+"""The zlib 1.2.8 stream API exported by libzamd_z.so, driven like the reference's own
+test/example.c drives libz: one-shot helpers, streaming with small buffers, flushes,
+gzip headers, error returns.  The system zlib (Python's) is the independent reader/writer."""
+import ctypes as C
+import gzip
+import io
+import zlib
+
+import pytest
+
+import _oracle as O
+import _zapi as Z
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compress_of_one_chunk_equals_reference_bytes():
+    # inputs of at most one chunk are a single Z_FINISH stream: byte-identical to the reference's compress2
+    for data, level in ((b"hello, hello!", 6), (O.corpus(300000, 0, 1), 6), (O.corpus(1 << 20, 4, 5), 9), (b"", 6), (O.corpus(70000, 3, 4), 4)):
+        rc, comp = Z.compress2(data, level)
+        assert rc == 0
+        flg = {4: 0x5e, 6: 0x9c, 9: 0xda}[level]
+        want = bytes([0x78, flg]) + O.deflate_chunk(data, 0, len(data), level, 0, 8, True) + zlib.adler32(data).to_bytes(4, "big")
+        assert comp == want
+        assert zlib.decompress(comp) == data
+
+
+def test_compress_uncompress_multi_chunk_round_trip():
+    data = O.corpus(3 * (1 << 20) + 12345, 4, 5)
+    rc, comp = Z.compress2(data, 6)
+    assert rc == 0
+    assert zlib.decompress(comp) == data
+    rc, back = Z.uncompress(comp, len(data))
+    assert rc == 0 and back == data
+    # too little room / truncated input (uncompr.c:49-54)
+    assert Z.uncompress(comp, len(data) - 1)[0] == Z.Z_BUF_ERROR
+    assert Z.uncompress(comp[:-5], len(data))[0] == Z.Z_DATA_ERROR
+    assert Z.compress2(data, 6, cap=1000)[0] == Z.Z_BUF_ERROR
+
+
+@pytest.mark.parametrize("wbits", [15, -15, 31])
+@pytest.mark.parametrize("in_step,out_step", [(None, 1 << 20), (70001, 4096), (1 << 20, 1 << 16)])
+def test_deflate_streaming_is_a_valid_stream(wbits, in_step, out_step):
+    data = O.corpus(2 * (1 << 20) + 777, 0, 11)
+    comp, (tin, tout, adler) = Z.deflate_stream(data, 6, wbits, in_step=in_step, out_step=out_step)
+    assert tin == len(data) and tout == len(comp)
+    assert zlib.decompressobj(wbits).decompress(comp) == data
+    if wbits == 15:
+        assert adler == zlib.adler32(data)
+    if wbits == 31:
+        assert adler == zlib.crc32(data)
+        assert comp[:10] == bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3])
+
+
+def test_flush_points_are_decodable_prefixes():
+    data = O.corpus(400000, 4, 3)
+    cuts = {1000: Z.Z_SYNC_FLUSH, 150000: Z.Z_FULL_FLUSH, 150001: Z.Z_PARTIAL_FLUSH, 300000: Z.Z_BLOCK}
+    comp, _ = Z.deflate_stream(data, 6, -15, flushes=cuts)
+    assert zlib.decompressobj(-15).decompress(comp) == data
+    # after a Z_SYNC_FLUSH everything fed so far can be decoded from the bytes produced so far
+    l = Z.lib()
+    s = Z.ZStream()
+    assert l.deflateInit2_(C.byref(s), 6, 8, -15, 8, 0, Z.VERSION, Z.SZ) == 0
+    src = C.create_string_buffer(data, len(data))
+    obuf = C.create_string_buffer(1 << 20)
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), 5000, C.addressof(obuf), 1 << 20
+    assert l.deflate(C.byref(s), Z.Z_SYNC_FLUSH) == Z.Z_OK
+    part = obuf.raw[:s.total_out]
+    assert part.endswith(b"\x00\x00\xff\xff")
+    assert zlib.decompressobj(-15).decompress(part) == data[:5000]
+    # nothing new and the same flush again: Z_BUF_ERROR (deflate.c:887-890), not fatal
+    assert l.deflate(C.byref(s), Z.Z_SYNC_FLUSH) == Z.Z_BUF_ERROR
+    s.avail_in = 0
+    assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+    assert zlib.decompressobj(-15).decompress(obuf.raw[:s.total_out]) == data[:5000]
+    assert l.deflateEnd(C.byref(s)) == Z.Z_OK
+
+
+def test_gzip_header_fields_round_trip():
+    data = O.corpus(100000, 0, 4)
+    h = Z.GzHeader()
+    name, comment, extra = C.create_string_buffer(b"file.txt"), C.create_string_buffer(b"a comment"), C.create_string_buffer(b"\x01\x02\x03\x04\x05", 5)
+    h.text, h.time, h.os, h.hcrc = 1, 0x12345678, 7, 1
+    h.name, h.comment, h.extra, h.extra_len = C.addressof(name), C.addressof(comment), C.addressof(extra), 5
+    comp, _ = Z.deflate_stream(data, 9, 31, header=h)
+    g = gzip.GzipFile(fileobj=io.BytesIO(comp))
+    assert g.read() == data
+    assert g.mtime == 0x12345678
+    # and back through our inflate with inflateGetHeader
+    h2 = Z.GzHeader()
+    nbuf, cbuf, ebuf = C.create_string_buffer(64), C.create_string_buffer(64), C.create_string_buffer(64)
+    h2.name, h2.name_max, h2.comment, h2.comm_max, h2.extra, h2.extra_max = C.addressof(nbuf), 64, C.addressof(cbuf), 64, C.addressof(ebuf), 64
+    rc, out, msg, unused, _ = Z.inflate_stream(comp, 47, header=h2)
+    assert rc == Z.Z_STREAM_END and out == data and unused == 0
+    assert (h2.done, h2.text, h2.time, h2.os, h2.hcrc, h2.extra_len, h2.xflags) == (1, 1, 0x12345678, 7, 1, 5, 2)
+    assert nbuf.value == b"file.txt" and cbuf.value == b"a comment" and ebuf.raw[:5] == b"\x01\x02\x03\x04\x05"
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+@pytest.mark.parametrize("in_step,out_step", [(None, 1 << 22), (5000, 3000), (64 << 10, 1 << 20)])
+def test_inflate_of_foreign_streams(level, in_step, out_step):
+    data = O.corpus(700000, 4, 21)
+    for wbits, comp in ((15, zlib.compress(data, level)), (31, gzip.compress(data, level)),
+                        (-15, zlib.compressobj(level, 8, -15).compress(data) + zlib.compressobj(level, 8, -15).flush())):
+        if wbits == -15:
+            c = zlib.compressobj(level, 8, -15)
+            comp = c.compress(data) + c.flush()
+        rc, out, msg, unused, (tin, tout, adler) = Z.inflate_stream(comp + b"TRAILING", wbits, in_step=in_step, out_step=out_step)
+        assert rc == Z.Z_STREAM_END, msg
+        assert out == data
+        assert unused == 8 and tin == len(comp) and tout == len(data)
+        if wbits == 15:
+            assert adler == zlib.adler32(data)
+        if wbits == 31:
+            assert adler == zlib.crc32(data)
+
+
+def test_inflate_of_own_chunked_stream_uses_sync_markers():
+    data = O.corpus(5 * (1 << 20) + 99, 4, 6)
+    comp, _ = Z.deflate_stream(data, 6, 31)
+    rc, out, msg, unused, _ = Z.inflate_stream(comp, 31, out_step=1 << 20)
+    assert rc == Z.Z_STREAM_END and out == data
+
+
+HEADER_VECTORS = [   # test/infcover.c:399-411: (hex, windowBits, expected return, expected msg)
+    ("1f 8b 00 00", 31, Z.Z_DATA_ERROR, "unknown compression method"),
+    ("1f 8b 08 80", 31, Z.Z_DATA_ERROR, "unknown header flags set"),
+    ("77 85", 15, Z.Z_DATA_ERROR, "unknown compression method"),
+    ("78 9c", 8, Z.Z_DATA_ERROR, "invalid window size"),
+    ("78 9c 63 00 00 00 01 00 01", 15, Z.Z_STREAM_END, None),
+    ("1f 8b 08 1e 00 00 00 00 00 00 01 00 00 00 00 00 00", 47, Z.Z_DATA_ERROR, "header crc mismatch"),
+    ("1f 8b 08 02 00 00 00 00 00 00 1d 26 03 00 00 00 00 00 00 00 00 00", 47, Z.Z_STREAM_END, None),
+    ("78 90", 47, Z.Z_DATA_ERROR, "incorrect header check"),
+    ("08 b8 00 00 00 01", 8, Z.Z_NEED_DICT, None),
+    ("1f 8b 08 00 00 00 00 00 00 00 03 00 00 00 00 01", 47, Z.Z_DATA_ERROR, "incorrect data check"),
+    ("1f 8b 08 00 00 00 00 00 00 00 03 00 00 00 00 00 00 00 00 01", 47, Z.Z_DATA_ERROR, "incorrect length check"),
+]
+
+
+@pytest.mark.parametrize("hexs,wbits,want,msg", HEADER_VECTORS)
+def test_wrapper_vectors_of_the_reference_test(hexs, wbits, want, msg):
+    comp = bytes.fromhex(hexs.replace(" ", ""))
+    rc, out, got_msg, unused, _ = Z.inflate_stream(comp, wbits)
+    assert rc == want
+    assert got_msg == msg
+
+
+def test_data_errors_carry_the_reference_messages():
+    import json, os
+    vec = json.load(open(os.path.join(Z.ROOT, "tests", "golden", "inflate_vectors.json")))["raw"]
+    for v in vec:
+        comp = bytes.fromhex(v["hex"].replace(" ", ""))
+        rc, out, msg, unused, _ = Z.inflate_stream(comp, -15)
+        if v["msg"] is None:
+            assert rc == Z.Z_STREAM_END, v
+            assert out == zlib.decompressobj(-15).decompress(comp)
+        else:
+            assert rc == Z.Z_DATA_ERROR and msg == v["msg"], (v, rc, msg)
+
+
+def test_preset_dictionary_on_inflate():
+    d = O.corpus(20000, 0, 30)
+    data = O.corpus(50000, 0, 30)
+    c = zlib.compressobj(6, 8, 15, 8, 0, d)
+    comp = c.compress(data) + c.flush()
+    rc, out, msg, unused, _ = Z.inflate_stream(comp, 15, dictionary=d)
+    assert rc == Z.Z_STREAM_END and out == data
+    rc, out, msg, unused, _ = Z.inflate_stream(comp, 15)
+    assert rc == Z.Z_NEED_DICT
+
+
+def test_checksum_entry_points():
+    l = Z.lib()
+    data = O.corpus(3000000, 1, 8)
+    assert l.adler32(0, None, 0) == 1 and l.crc32(0, None, 0) == 0
+    assert l.adler32(1, data, len(data)) == zlib.adler32(data)
+    assert l.crc32(0, data, len(data)) == zlib.crc32(data)
+    a = l.adler32(1, data[:1000], 1000)
+    assert l.adler32(a, data[1000:], len(data) - 1000) == zlib.adler32(data)
+    c1, c2 = zlib.crc32(data[:12345]), zlib.crc32(data[12345:])
+    assert l.crc32_combine(c1, c2, len(data) - 12345) == zlib.crc32(data)
+    a1, a2 = zlib.adler32(data[:12345]), zlib.adler32(data[12345:])
+    assert l.adler32_combine64(a1, a2, len(data) - 12345) == zlib.adler32(data)
+
+
+def test_params_change_mid_stream():
+    data = O.corpus(300000, 0, 2)
+    l = Z.lib()
+    s = Z.ZStream()
+    assert l.deflateInit2_(C.byref(s), 9, 8, 15, 8, 0, Z.VERSION, Z.SZ) == 0
+    src = C.create_string_buffer(data, len(data))
+    obuf = C.create_string_buffer(1 << 20)
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), 100000, C.addressof(obuf), 1 << 20
+    assert l.deflate(C.byref(s), Z.Z_NO_FLUSH) == Z.Z_OK
+    assert l.deflateParams(C.byref(s), 4, 3) == Z.Z_OK      # to level 4, Z_RLE
+    s.avail_in = 200000
+    assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+    assert zlib.decompress(obuf.raw[:s.total_out]) == data
+    assert l.deflateEnd(C.byref(s)) == Z.Z_OK

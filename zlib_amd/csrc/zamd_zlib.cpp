@@ -460,6 +460,497 @@ int deflateCopy(z_streamp dest, z_streamp source) {
     return Z_OK;
 }
 
+// ------------------------------------------------------------------ inflate side
+}  // extern "C"
+
+namespace {
+
+enum IMode { IM_HEAD, IM_DICT, IM_BODY, IM_TRAILER, IM_DONE, IM_BAD, IM_MEM };
+
+struct IState {
+    uint32_t magic;
+    int wrap;                       // 0 raw, bit 0 zlib allowed, bit 1 gzip allowed (inflate.c:153-164)
+    unsigned wbits;
+    IMode mode;
+    bool gzip, havedict, last, synced;
+    gz_headerp head;
+    std::vector<uint8_t> hdr;       // wrapper header bytes seen so far
+    std::vector<uint8_t> in;        // compressed bytes from the next block start on
+    uint32_t bit_off;               // bit inside in[0] where that block starts
+    size_t scanned;                 // in[0, scanned) has been searched for sync markers
+    size_t tried;                   // size of `in` at the last attempt that made no progress
+    std::vector<uint64_t> cands;    // byte offsets in `in` just behind a 00 00 FF FF pattern
+    std::vector<uint8_t> out; size_t out_pos;
+    std::vector<uint8_t> hist;      // last <= 32 KiB of output (the window)
+    uint32_t check; uint64_t total; // running check value and length of the inflated data
+    uint32_t dictid;
+    uint64_t out_batch;
+};
+
+inline IState *istate(z_streamp strm) {
+    if (strm == Z_NULL || strm->state == Z_NULL) return nullptr;
+    IState *s = (IState *)strm->state;
+    return s->magic == INFLATE_MAGIC ? s : nullptr;
+}
+
+int ibad(z_streamp strm, IState *s, const char *msg) { strm->msg = msg; s->mode = IM_BAD; return Z_DATA_ERROR; }
+
+// Parses the wrapper header collected in s->hdr.  Returns 1 when complete, 0 when
+// more bytes are needed, Z_DATA_ERROR on a bad header (msg set).  (inflate.c:640-825)
+int parse_header(z_streamp strm, IState *s) {
+    const std::vector<uint8_t> &h = s->hdr;
+    size_t n = h.size();
+    if (n < 2) return 0;
+    if ((s->wrap & 2) && h[0] == 0x1f && h[1] == 0x8b) {
+        if (n < 4) return 0;
+        if (h[2] != Z_DEFLATED) return ibad(strm, s, "unknown compression method");
+        unsigned flags = h[3];
+        if (flags & 0xe0) return ibad(strm, s, "unknown header flags set");
+        if (n < 10) return 0;
+        size_t pos = 10;
+        size_t extra_at = 0, extra_len = 0, name_at = 0, comm_at = 0;
+        if (flags & 4) {
+            if (n < pos + 2) return 0;
+            extra_len = h[pos] | (h[pos + 1] << 8);
+            pos += 2; extra_at = pos;
+            if (n < pos + extra_len) return 0;
+            pos += extra_len;
+        }
+        if (flags & 8) {
+            name_at = pos;
+            while (pos < n && h[pos]) pos++;
+            if (pos >= n) return 0;
+            pos++;
+        }
+        if (flags & 16) {
+            comm_at = pos;
+            while (pos < n && h[pos]) pos++;
+            if (pos >= n) return 0;
+            pos++;
+        }
+        if (flags & 2) {
+            if (n < pos + 2) return 0;
+            uint32_t c = header_crc(0, h.data(), pos) & 0xffff;
+            if ((unsigned)(h[pos] | (h[pos + 1] << 8)) != c) return ibad(strm, s, "header crc mismatch");
+            pos += 2;
+        }
+        if (n != pos) return 0;      // bytes are appended one at a time, so this cannot overshoot
+        gz_headerp g = s->head;
+        if (g != Z_NULL) {
+            g->text = flags & 1;
+            g->time = (uLong)h[4] | ((uLong)h[5] << 8) | ((uLong)h[6] << 16) | ((uLong)h[7] << 24);
+            g->xflags = h[8]; g->os = h[9];
+            if (flags & 4) {
+                g->extra_len = (uInt)extra_len;
+                if (g->extra != Z_NULL) memcpy(g->extra, h.data() + extra_at, extra_len > g->extra_max ? g->extra_max : extra_len);
+            } else g->extra = Z_NULL;
+            if (flags & 8) {
+                if (g->name != Z_NULL) for (uInt i = 0; i < g->name_max; i++) { g->name[i] = h[name_at + i]; if (!h[name_at + i]) break; }
+            } else g->name = Z_NULL;
+            if (flags & 16) {
+                if (g->comment != Z_NULL) for (uInt i = 0; i < g->comm_max; i++) { g->comment[i] = h[comm_at + i]; if (!h[comm_at + i]) break; }
+            } else g->comment = Z_NULL;
+            g->hcrc = (flags >> 1) & 1;
+            g->done = 1;
+        }
+        s->gzip = true;
+        strm->adler = s->check = 0;
+        s->mode = IM_BODY;
+        return 1;
+    }
+    if (s->head != Z_NULL) s->head->done = -1;
+    if (!(s->wrap & 1) || (((unsigned)h[0] << 8) + h[1]) % 31) return ibad(strm, s, "incorrect header check");
+    if ((h[0] & 15) != Z_DEFLATED) return ibad(strm, s, "unknown compression method");
+    unsigned len = (h[0] >> 4) + 8;
+    if (s->wbits == 0) s->wbits = len;
+    else if (len > s->wbits) return ibad(strm, s, "invalid window size");
+    s->gzip = false;
+    if (h[1] & 0x20) {
+        if (n < 6) return 0;
+        s->dictid = ((uint32_t)h[2] << 24) | ((uint32_t)h[3] << 16) | ((uint32_t)h[4] << 8) | h[5];
+        strm->adler = s->check = s->dictid;
+        s->mode = IM_DICT;
+        return 1;
+    }
+    strm->adler = s->check = 1;
+    s->mode = IM_BODY;
+    return 1;
+}
+
+void idrain(z_streamp strm, IState *s) {
+    size_t len = s->out.size() - s->out_pos;
+    if (len > strm->avail_out) len = strm->avail_out;
+    if (len == 0) return;
+    memcpy(strm->next_out, s->out.data() + s->out_pos, len);
+    strm->next_out += len; strm->avail_out -= (uInt)len; strm->total_out += len;
+    s->out_pos += len;
+    if (s->out_pos == s->out.size()) { s->out.clear(); s->out_pos = 0; }
+}
+
+// One decode attempt over the buffered input.  Returns Z_OK (with or without
+// progress), Z_DATA_ERROR (msg set) or Z_MEM_ERROR.
+int decode_some(z_streamp strm, IState *s) {
+    if (s->in.size() * 8ull <= s->bit_off) return Z_OK;
+    // sync-marker candidates: independent starting points for parallel wavefronts
+    for (size_t p = s->scanned < 4 ? 4 : s->scanned + 1; p <= s->in.size(); p++) {
+        const uint8_t *q = s->in.data() + p - 4;
+        if (q[0] == 0 && q[1] == 0 && q[2] == 0xff && q[3] == 0xff) s->cands.push_back(p);
+    }
+    s->scanned = s->in.size();
+    std::vector<zamd_inflate_seg> segs;
+    const uint64_t end_bits = s->in.size() * 8ull;
+    auto add = [&](uint64_t bit, uint32_t win) {
+        zamd_inflate_seg g; memset(&g, 0, sizeof g);
+        g.in_bit = bit; g.in_end_bit = end_bits; g.out_off = 0; g.out_cap = ~0ull >> 2; g.win_avail = win; g.mode = ZAMD_INF_SYNCSTOP;
+        segs.push_back(g);
+    };
+    add(s->bit_off, (uint32_t)s->hist.size());
+    for (uint64_t c : s->cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST);
+
+    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    zamd_engine *e = engine_locked();
+    if (!e) return Z_MEM_ERROR;
+    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, s->in.size() + 64) != Z_OK) return Z_MEM_ERROR;
+    if (zamd_dev_upload(e, g_gpu.d_in, s->in.data(), s->in.size()) != 0) return Z_MEM_ERROR;
+    if (zamd_inflate_segments_dev(e, g_gpu.d_in, s->in.size(), segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
+
+    // follow the chain of segments from the known block start
+    std::vector<zamd_inflate_seg> chain;
+    uint64_t produced = 0, end_bit = s->bit_off;
+    bool final_block = false;
+    size_t idx = 0;
+    for (;;) {
+        zamd_inflate_seg g = segs[idx];
+        if (g.out_len > s->out_batch && g.out_len > 0 && chain.empty()) {
+            // one segment larger than the output batch: take a whole-block prefix of it
+            zamd_inflate_seg one = g; one.out_cap = s->out_batch; one.status = 0;
+            if (zamd_inflate_segments_dev(e, g_gpu.d_in, s->in.size(), &one, 1, nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
+            if (one.out_len == 0) { strm->msg = "deflate block too large for the GPU engine"; s->mode = IM_MEM; return Z_MEM_ERROR; }
+            g = one; g.status = 3;
+        }
+        if (produced + g.out_len > s->out_batch && !chain.empty()) break;
+        if (g.end_bit > g.in_bit || g.status == 1) {
+            g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
+            g.out_off = produced; g.out_cap = g.out_len; g.in_end_bit = g.end_bit; g.mode = ZAMD_INF_EXACT;
+            chain.push_back(g);
+            produced += g.out_len; end_bit = g.end_bit;
+        }
+        if (g.status >= 16) {
+            // valid blocks in front of the error are delivered first; the error comes back on the next attempt
+            if (chain.empty()) return ibad(strm, s, zamd_inflate_message(g.status));
+            break;
+        }
+        if (g.status == 1) { final_block = true; break; }
+        if (g.status != 2) break;                            // input (or the output batch) ran out inside this segment
+        // stopped at a sync marker: the next segment is the candidate that starts there
+        uint64_t nb = g.end_bit;
+        size_t lo = idx + 1, hi = segs.size();
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (segs[mid].in_bit < nb) lo = mid + 1; else hi = mid; }
+        if (lo >= segs.size() || segs[lo].in_bit != nb) break;
+        idx = lo;
+    }
+    if (chain.empty()) { s->tried = s->in.size(); return Z_OK; }
+
+    if (produced) {
+        if (grow(e, &g_gpu.d_out, &g_gpu.out_cap, produced + 64) != Z_OK) return Z_MEM_ERROR;
+        uint8_t *d_head = nullptr;
+        if (!s->hist.empty()) {
+            if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, HIST) != Z_OK) return Z_MEM_ERROR;
+            d_head = (uint8_t *)g_gpu.d_off;
+            if (zamd_dev_upload(e, d_head + (HIST - s->hist.size()), s->hist.data(), s->hist.size()) != 0) return Z_MEM_ERROR;
+        }
+        if (zamd_inflate_segments_dev(e, g_gpu.d_in, s->in.size(), chain.data(), chain.size(), d_head, g_gpu.d_out, produced) != 0)
+            return Z_MEM_ERROR;
+        for (const zamd_inflate_seg &g : chain)
+            if (g.status >= 3) return ibad(strm, s, zamd_inflate_message(g.status));
+        if (s->wrap) {
+            uint32_t v = s->check;
+            int rc = s->gzip ? zamd_crc32_dev(e, v, g_gpu.d_out, produced, &v) : zamd_adler32_dev(e, v, g_gpu.d_out, produced, &v);
+            if (rc != 0) return Z_MEM_ERROR;
+            strm->adler = s->check = v;
+        }
+        size_t at = s->out.size();
+        s->out.resize(at + produced);
+        if (zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
+        s->total += produced;
+        if (produced >= HIST) s->hist.assign(s->out.end() - HIST, s->out.end());
+        else {
+            s->hist.insert(s->hist.end(), s->out.end() - produced, s->out.end());
+            if (s->hist.size() > HIST) s->hist.erase(s->hist.begin(), s->hist.end() - HIST);
+        }
+    }
+    // drop the consumed input
+    size_t drop = (size_t)(end_bit >> 3);
+    if (final_block) { drop = (size_t)((end_bit + 7) >> 3); s->bit_off = 0; s->last = true; s->mode = IM_TRAILER; }
+    else s->bit_off = (uint32_t)(end_bit & 7);
+    s->in.erase(s->in.begin(), s->in.begin() + drop);
+    std::vector<uint64_t> keep;
+    for (uint64_t c : s->cands) if (c > drop) keep.push_back(c - drop);
+    s->cands.swap(keep);
+    s->scanned = s->scanned > drop ? s->scanned - drop : 0;
+    s->tried = 0;
+    return Z_OK;
+}
+
+int istate_reset(z_streamp strm, IState *s, bool keep_window) {
+    strm->total_in = strm->total_out = 0;
+    s->total = 0;
+    strm->msg = Z_NULL;
+    if (s->wrap) strm->adler = s->wrap & 1;
+    s->mode = s->wrap ? IM_HEAD : IM_BODY;
+    s->last = s->havedict = s->gzip = s->synced = false;
+    s->head = Z_NULL;
+    s->hdr.clear(); s->in.clear(); s->cands.clear(); s->out.clear();
+    s->bit_off = 0; s->scanned = 0; s->tried = 0; s->out_pos = 0; s->check = 0; s->dictid = 0;
+    if (!keep_window) s->hist.clear();
+    return Z_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int inflateResetKeep(z_streamp strm) {
+    IState *s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    return istate_reset(strm, s, true);
+}
+
+int inflateReset(z_streamp strm) {
+    IState *s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    return istate_reset(strm, s, false);
+}
+
+int inflateReset2(z_streamp strm, int windowBits) {
+    IState *s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    int wrap;
+    if (windowBits < 0) { wrap = 0; windowBits = -windowBits; }
+    else { wrap = (windowBits >> 4) + 1; if (windowBits < 48) windowBits &= 15; }
+    if (windowBits && (windowBits < 8 || windowBits > 15)) return Z_STREAM_ERROR;
+    s->wrap = wrap;
+    s->wbits = (unsigned)windowBits;
+    return inflateReset(strm);
+}
+
+int inflateInit2_(z_streamp strm, int windowBits, const char *version, int stream_size) {
+    if (version == Z_NULL || version[0] != ZLIB_VERSION[0] || stream_size != (int)sizeof(z_stream)) return Z_VERSION_ERROR;
+    if (strm == Z_NULL) return Z_STREAM_ERROR;
+    strm->msg = Z_NULL;
+    if (strm->zalloc == (alloc_func)0) { strm->zalloc = default_alloc; strm->opaque = (voidpf)0; }
+    if (strm->zfree == (free_func)0) strm->zfree = default_free;
+    void *mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(IState));
+    if (mem == Z_NULL) return Z_MEM_ERROR;
+    IState *s = new (mem) IState();
+    s->magic = INFLATE_MAGIC;
+    s->out_batch = env_u64("ZAMD_Z_OUT_BATCH_MIB", 1024) << 20;
+    strm->state = (struct internal_state *)s;
+    int ret = inflateReset2(strm, windowBits);
+    if (ret != Z_OK) {
+        s->magic = 0; s->~IState();
+        strm->zfree(strm->opaque, mem);
+        strm->state = Z_NULL;
+    }
+    return ret;
+}
+
+int inflateInit_(z_streamp strm, const char *version, int stream_size) { return inflateInit2_(strm, 15, version, stream_size); }
+
+int inflateEnd(z_streamp strm) {
+    IState *s = istate(strm);
+    if (!s || strm->zfree == (free_func)0) return Z_STREAM_ERROR;
+    s->magic = 0;
+    s->~IState();
+    strm->zfree(strm->opaque, s);
+    strm->state = Z_NULL;
+    return Z_OK;
+}
+
+int inflate(z_streamp strm, int flush) {
+    IState *s = istate(strm);
+    if (!s || strm->next_out == Z_NULL || (strm->next_in == Z_NULL && strm->avail_in != 0)) return Z_STREAM_ERROR;
+    if (s->mode == IM_MEM) return Z_MEM_ERROR;
+    const uInt in0 = strm->avail_in, out0 = strm->avail_out;
+    int ret = Z_OK;
+    for (;;) {
+        idrain(strm, s);
+        if (s->mode == IM_TRAILER) {
+            // Checked in the same call that decoded the final block, so that bytes
+            // behind the stream can be handed back to that call's next_in.
+            size_t need = s->wrap ? (s->gzip ? 8 : 4) : 0;
+            while (s->in.size() < need && strm->avail_in != 0) {
+                s->in.push_back(*strm->next_in++); strm->avail_in--; strm->total_in++;
+            }
+            if (need && s->in.size() >= 4) {               // the check value is compared as soon as it is there (inflate.c:1176-1192)
+                const uint8_t *t = s->in.data();
+                uint32_t got = s->gzip ? ((uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24))
+                                       : (((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3]);
+                if (got != s->check) { ibad(strm, s, "incorrect data check"); need = 4; }
+            }
+            if (s->in.size() < need) break;
+            if (s->mode != IM_BAD && s->gzip) {
+                const uint8_t *t = s->in.data();
+                uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+                if (isize != (uint32_t)(s->total & 0xffffffffu)) ibad(strm, s, "incorrect length check");
+            }
+            size_t extra = s->in.size() - need;
+            strm->next_in -= extra; strm->avail_in += (uInt)extra; strm->total_in -= extra;
+            s->in.clear(); s->cands.clear(); s->scanned = 0;
+            if (s->mode != IM_BAD) s->mode = IM_DONE;
+            continue;
+        }
+        if (s->out.size() != s->out_pos) break;            // caller must make room first; no input is taken meanwhile
+        if (s->mode == IM_DONE) { ret = Z_STREAM_END; break; }
+        if (s->mode == IM_BAD) { ret = Z_DATA_ERROR; break; }
+        if (s->mode == IM_DICT) {
+            if (!s->havedict) return Z_NEED_DICT;
+            strm->adler = s->check = 1;
+            s->mode = IM_BODY;
+        }
+        if (s->mode == IM_HEAD) {
+            int r = 0;
+            while (strm->avail_in != 0 && r == 0) {
+                s->hdr.push_back(*strm->next_in++); strm->avail_in--; strm->total_in++;
+                r = parse_header(strm, s);
+            }
+            if (r == 0) break;
+            continue;
+        }
+        if (s->mode == IM_BODY) {
+            const size_t before = s->in.size();
+            uint64_t room = (512ull << 20) > before ? (512ull << 20) - before : 0;
+            uint64_t take = strm->avail_in < room ? strm->avail_in : room;
+            if (take) {
+                s->in.insert(s->in.end(), strm->next_in, strm->next_in + take);
+                strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take;
+            }
+            if (s->in.size() == s->tried) break;             // nothing new since the last fruitless attempt
+            int rc = decode_some(strm, s);
+            if (rc == Z_MEM_ERROR) { s->mode = IM_MEM; return Z_MEM_ERROR; }
+            continue;
+        }
+        break;
+    }
+    strm->data_type = (int)s->bit_off + (s->last ? 64 : 0) + (s->mode == IM_BODY ? 128 : 0);
+    if (((in0 == strm->avail_in && out0 == strm->avail_out) || flush == Z_FINISH) && ret == Z_OK) ret = Z_BUF_ERROR;
+    return ret;
+}
+
+int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength) {
+    IState *s = istate(strm);
+    if (!s || (dictionary == Z_NULL && dictLength)) return Z_STREAM_ERROR;
+    if (s->wrap != 0 && s->mode != IM_DICT) return Z_STREAM_ERROR;
+    if (s->mode == IM_DICT) {
+        uLong id = adler32(1L, dictionary, dictLength);
+        if (id != s->check) return Z_DATA_ERROR;
+    }
+    s->hist.insert(s->hist.end(), dictionary, dictionary + dictLength);
+    if (s->hist.size() > HIST) s->hist.erase(s->hist.begin(), s->hist.end() - HIST);
+    s->havedict = true;
+    return Z_OK;
+}
+
+int inflateGetDictionary(z_streamp strm, Bytef *dictionary, uInt *dictLength) {
+    IState *s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (!s->hist.empty() && dictionary != Z_NULL) memcpy(dictionary, s->hist.data(), s->hist.size());
+    if (dictLength != Z_NULL) *dictLength = (uInt)s->hist.size();
+    return Z_OK;
+}
+
+int inflateGetHeader(z_streamp strm, gz_headerp head) {
+    IState *s = istate(strm);
+    if (!s || (s->wrap & 2) == 0) return Z_STREAM_ERROR;
+    s->head = head;
+    head->done = 0;
+    return Z_OK;
+}
+
+int inflateSync(z_streamp strm) {          // inflate.c:1377-1418
+    IState *s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (strm->avail_in == 0 && s->in.empty()) return Z_BUF_ERROR;
+    // search the buffered bytes, then the caller's
+    std::vector<uint8_t> &b = s->in;
+    size_t from = s->bit_off ? 1 : 0;
+    b.insert(b.end(), strm->next_in, strm->next_in + strm->avail_in);
+    size_t taken = strm->avail_in, found = 0;
+    for (size_t p = from + 4; p <= b.size(); p++)
+        if (b[p - 4] == 0 && b[p - 3] == 0 && b[p - 2] == 0xff && b[p - 1] == 0xff) { found = p; break; }
+    strm->next_in += taken; strm->total_in += taken; strm->avail_in = 0;
+    if (!found) { b.clear(); s->bit_off = 0; s->cands.clear(); s->scanned = 0; s->tried = 0; return Z_DATA_ERROR; }
+    // bytes behind the marker go back to the caller when they came from this call
+    size_t behind = b.size() - found;
+    size_t give = behind < taken ? behind : taken;
+    strm->next_in -= give; strm->avail_in += (uInt)give; strm->total_in -= give;
+    std::vector<uint8_t> rest(b.begin() + found, b.end() - give);
+    uLong tin = strm->total_in, tout = strm->total_out;
+    istate_reset(strm, s, false);
+    strm->total_in = tin; strm->total_out = tout;
+    s->in.swap(rest);
+    s->mode = IM_BODY;
+    return Z_OK;
+}
+
+int inflateSyncPoint(z_streamp strm) {
+    IState *s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    return 0;      // input is only ever consumed in whole blocks, never up to the length bytes of a stored block
+}
+
+int inflateCopy(z_streamp dest, z_streamp source) {
+    IState *ss = istate(source);
+    if (dest == Z_NULL || !ss || source->zalloc == (alloc_func)0 || source->zfree == (free_func)0) return Z_STREAM_ERROR;
+    void *mem = source->zalloc(source->opaque, 1, (uInt)sizeof(IState));
+    if (mem == Z_NULL) return Z_MEM_ERROR;
+    memcpy((void *)dest, (const void *)source, sizeof(z_stream));
+    IState *ds = new (mem) IState(*ss);
+    dest->state = (struct internal_state *)ds;
+    return Z_OK;
+}
+
+int inflatePrime(z_streamp strm, int, int) {
+    if (!istate(strm)) return Z_STREAM_ERROR;
+    strm->msg = "inflatePrime is not supported by the GPU engine";
+    return Z_STREAM_ERROR;
+}
+
+int inflateUndermine(z_streamp strm, int) {      // inflate.c:1485-1500 without INFLATE_ALLOW_INVALID_DISTANCE_TOOFAR_ARRR
+    if (!istate(strm)) return Z_STREAM_ERROR;
+    return Z_DATA_ERROR;
+}
+
+long inflateMark(z_streamp strm) {
+    if (!istate(strm)) return -(1L << 16);
+    return -(1L << 16);                          // always between blocks: back == -1, no copy in progress
+}
+
+int uncompress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen) {    // uncompr.c:24-59
+    z_stream stream;
+    memset(&stream, 0, sizeof(stream));
+    stream.next_in = source;
+    stream.avail_in = (uInt)sourceLen;
+    if ((uLong)stream.avail_in != sourceLen) return Z_BUF_ERROR;
+    stream.next_out = dest;
+    stream.avail_out = (uInt)*destLen;
+    if ((uLong)stream.avail_out != *destLen) return Z_BUF_ERROR;
+    int err = inflateInit_(&stream, ZLIB_VERSION, (int)sizeof(z_stream));
+    if (err != Z_OK) return err;
+    err = inflate(&stream, Z_FINISH);
+    if (err != Z_STREAM_END) {
+        // Input is consumed ahead of the output here, so "input used up" alone does not mean
+        // a truncated stream: inflated data still waiting for room is the Z_BUF_ERROR case.
+        IState *s = istate(&stream);
+        bool waiting = s && (s->out.size() != s->out_pos || s->mode == IM_DONE);
+        inflateEnd(&stream);
+        if (err == Z_NEED_DICT || (err == Z_BUF_ERROR && stream.avail_in == 0 && !waiting)) return Z_DATA_ERROR;
+        return err;
+    }
+    *destLen = stream.total_out;
+    return inflateEnd(&stream);
+}
+
 // ------------------------------------------------------------------ one-shot helpers
 uLong compressBound(uLong sourceLen) {   // compress.c:76-80 plus the per-chunk markers of this engine
     uLong ref = sourceLen + (sourceLen >> 12) + (sourceLen >> 14) + (sourceLen >> 25) + 13;
