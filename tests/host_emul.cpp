@@ -27,6 +27,33 @@ static void or_bits(std::vector<uint8_t> &out, uint64_t bit, uint64_t v, uint32_
     for (uint32_t i = 0; i < n; i++, bit++) if ((v >> i) & 1u) out[bit >> 3] |= (uint8_t)(1u << (bit & 7));
 }
 
+/* head[]/prev[] of deflate_fast held the way the kernel holds them: 16-bit window indices */
+struct HostFast {
+    const uint8_t *b; const ZcParams *P;
+    std::vector<uint16_t> head, prev;
+    uint32_t insert(uint32_t p, uint32_t B)
+    {
+        uint32_t h = zc_hash3(b[p], b[p + 1], b[p + 2], P->hash_shift, P->hash_mask), e = head[h];
+        prev[(p - B) & 32767u] = (uint16_t)e; head[h] = (uint16_t)(p - B);
+        return e;
+    }
+    void slide()
+    {
+        for (auto &m : head) m = m >= 32768 ? m - 32768 : 0;
+        for (auto &m : prev) m = m >= 32768 ? m - 32768 : 0;
+    }
+    void longest(uint32_t p, uint32_t B, uint32_t cur, uint32_t look, uint32_t *mlen, uint32_t *mdist)
+    {   /* lane-parallel shape of the kernel: collect the candidates, measure them all, then pick in chain order */
+        uint32_t sw = p - B, limit = sw > ZC_MAX_DIST ? sw - ZC_MAX_DIST : 0, cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
+        uint32_t nice = P->nice < look ? P->nice : look, cand[32], lens[32], n = 0;
+        do { cand[n++] = cur; cur = prev[cur & 32767u]; } while (cur > limit && n < P->chain);
+        for (uint32_t k = 0; k < n; k++) { uint32_t l = 0; const uint8_t *m = b + B + cand[k], *s = b + p; while (l < cap && m[l] == s[l]) l++; lens[k] = l; }
+        uint32_t best = 2, bk = 0;
+        for (uint32_t k = 0; k < n; k++) { if (lens[k] > best) { best = lens[k]; bk = k; if (best >= nice) break; } }
+        if (best >= 3) { *mlen = best; *mdist = sw - cand[bk]; }
+    }
+};
+
 static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t chunk_size, int level, int strategy, int mem_level,
                                          std::vector<uint64_t> &chunk_off)
 {
@@ -37,7 +64,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
     P.good = cfg[level][0]; P.lazy = cfg[level][1]; P.nice = cfg[level][2]; P.chain = cfg[level][3];
     P.hash_bits = mem_level + 7; P.hash_mask = (1u << P.hash_bits) - 1; P.hash_shift = (P.hash_bits + 2) / 3;
     P.lit_bufsize = 1u << (mem_level + 6);
-    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : ZC_PARSE_SLOW;
+    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level < 4 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
     P.chunk_size = chunk_size; P.max_blocks = chunk_size / (P.lit_bufsize - 1) + 3;
 
     /* k_chain: global links */
@@ -74,6 +101,11 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
         auto symst = [&](uint32_t i, uint32_t w) { sym[i] = w; };
         auto blkst = [&](uint32_t i, const ZcBlock &b) { if (i >= blk.size()) { fprintf(stderr, "block table overflow\n"); exit(2); } blk[i] = b; };
         uint32_t nsym = 0, nb;
+        if (P.parser == ZC_PARSE_FAST) {
+            HostFast cx; cx.b = in + g.dstart; cx.P = &P;
+            cx.head.assign((size_t)1 << P.hash_bits, 0); cx.prev.assign(32768, 0);
+            nb = zc_parse_fast(g.dict_len, g.len, g.final, P, cx, symst, blkst, &nsym);
+        } else
         if (P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, P, blkst);
         else if (P.parser == ZC_PARSE_RLE) nb = zc_parse_rle(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
         else if (!g_hops) nb = zc_parse_slow(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
@@ -202,7 +234,7 @@ int main(int argc, char **argv)
         uint64_t n = (uint64_t)(rnd() % 4) * cs + ((rnd() & 1) ? tails[rnd() % 15] % cs : rnd() % cs);
         if (it == 0) n = 0;
         if (it == 1) { cs = 65536; n = 65374; }      /* tail-mode slide geometry */
-        int level = 4 + rnd() % 6, strategy = rnd() % 5, mem = (rnd() % 3) ? 8 : 1 + rnd() % 9;
+        int level = 1 + rnd() % 9, strategy = rnd() % 5, mem = (rnd() % 3) ? 8 : 1 + rnd() % 9;
         if (rnd() & 1) strategy = 0;
         if (level == 9 && n > 300000) level = 8;
         std::vector<uint8_t> in(n + 8);

@@ -11,7 +11,7 @@ import _oracle as O
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "deflate_golden.json")))
-GPU_LEVELS = range(4, 10)   # deflate_slow levels; levels 1-3 are declared unsupported by the engine for now
+GPU_LEVELS = range(1, 10)   # deflate_fast (1-3) and deflate_slow (4-9)
 
 
 def _gpu(engine, data, **kw):
@@ -19,7 +19,7 @@ def _gpu(engine, data, **kw):
     return out, [offs[i + 1] - offs[i] for i in range(len(offs) - 1)]
 
 
-@pytest.mark.parametrize("row", [r for r in GOLD["chunked"] if r["level"] >= 4 or r["strategy"] in (2, 3)],
+@pytest.mark.parametrize("row", GOLD["chunked"],
                          ids=lambda r: "k%d_L%d_S%d_M%d_n%d" % (r["kind"], r["level"], r["strategy"], r["mem_level"], r["n"]))
 def test_golden_rows_from_reference_build(engine, row):
     data = O.corpus(row["n"], row["kind"], row["seed"])
@@ -42,10 +42,18 @@ for strat in (1, 2, 3, 4):
     CASES.append((2, 150000, 9, strat, 8, 65536))
 for mem in (1, 2, 4, 7, 9):
     CASES.append((4, 400000, 6, 0, mem, 131072))
+for mem in (1, 3, 8):
+    for lvl in (1, 2, 3):
+        CASES.append((0, 250000, lvl, 0, mem, 65536))
+        CASES.append((4, 250000, lvl, 4, mem, 131072))
+for kind in range(5):
+    CASES.append((kind, (1 << 20) + 4321, 1, 0, 8, 1 << 19))
 # ragged / edge sizes: empty, below MIN_MATCH, around MIN_LOOKAHEAD, block-split boundary, tail-mode slide geometry
 for n in (0, 1, 2, 3, 4, 261, 262, 263, 16383, 16384, 32767, 32768, 32769, 65274, 65277, 65374, 65535, 65536, 65537, 98304 + 32600):
     CASES.append((0, n, 6, 0, 8, 65536))
     CASES.append((4, n, 9, 0, 8, 32768))
+    CASES.append((0, n, 1, 0, 8, 65536))
+    CASES.append((4, n, 3, 0, 8, 32768))
 
 
 @pytest.mark.parametrize("kind,n,level,strategy,mem,chunk", CASES)
@@ -67,7 +75,7 @@ def test_pathological_inputs(engine):
         base = bytes(rnd.getrandbits(8) for _ in range(per))
         inputs.append((base * (120000 // per + 2))[:120000])
     for data in inputs:
-        for level in (4, 6, 9):
+        for level in (1, 3, 4, 6, 9):
             want, wlens = O.deflate_chunked(data, 65536, level, 0, 8)
             out, lens = _gpu(engine, data, level=level, chunk_size=65536)
             assert out == want

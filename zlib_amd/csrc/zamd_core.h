@@ -497,6 +497,52 @@ ZC_HD uint32_t zc_parse_rle(uint32_t dict_len, uint32_t len, uint32_t final_, co
     return out.nblk;
 }
 
+/* deflate_fast() (deflate.c:1628-1722), levels 1-3.  Which strings enter the
+ * hash chains depends on the parse (the inside of a match longer than
+ * max_insert_length is skipped, :1680-1697), so the chains cannot be built ahead
+ * of it: this parser owns head[]/prev[] exactly as the reference does, through
+ * Ctx:
+ *   cx.insert(p, B)   INSERT_STRING: returns the previous head entry, a window
+ *                     index (a-coordinate minus B), 0 = NIL
+ *   cx.slide()        the window moved by 32 KiB: every entry m becomes
+ *                     m >= 32768 ? m - 32768 : NIL (deflate.c:1431-1448)
+ *   cx.longest(p, B, head, look, &len, &dist)   longest_match with prev_length 2
+ * P.lazy holds max_insert_length for these levels (deflate.h:179-183). */
+template <class Ctx, class Sym, class Blk>
+ZC_HD uint32_t zc_parse_fast(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P,
+                             Ctx &cx, Sym sym, Blk blk, uint32_t *nsym_out)
+{
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    ZcSink<Sym, Blk> out(sym, blk, dict_len, P.lit_bufsize);
+    /* deflateSetDictionary inserts every dictionary string; the last two wait for
+     * the first input bytes (deflate.c:364-381, 1471-1489) */
+    for (uint32_t a = 0; a < dict_len && a + ZC_MIN_MATCH <= w.E; a++) cx.insert(a, 0u);
+    uint32_t p = dict_len;
+    for (;;) {
+        if (w.wend - p < ZC_MIN_LOOK) {
+            uint32_t b0 = w.B;
+            w.refill(p);
+            if (w.B != b0) cx.slide();
+            if (w.wend == p) break;
+        }
+        uint32_t look = w.wend - p, hh = 0, mlen = 0, mdist = 0;
+        if (look >= ZC_MIN_MATCH) hh = cx.insert(p, w.B);
+        if (hh != 0 && (p - w.B) - hh <= ZC_MAX_DIST) cx.longest(p, w.B, hh, look, &mlen, &mdist);
+        bool f;
+        if (mlen >= ZC_MIN_MATCH) {
+            f = out.emit(zc_sym_match(mlen, mdist));
+            if (mlen <= P.lazy && look - mlen >= ZC_MIN_MATCH)
+                for (uint32_t i = 1; i < mlen; i++) cx.insert(p + i, w.B);
+            p += mlen;
+        } else { f = out.emit(p); p++; }
+        if (f) out.flush(p, 0, w);
+    }
+    if (final_) out.flush(p, 1, w);
+    else if (out.nsym != out.blk_sym0) out.flush(p, 0, w);
+    *nsym_out = out.nsym;
+    return out.nblk;
+}
+
 /* deflate_huff() (deflate.c:1934-1967): every byte a literal, so the block
  * table follows from the chunk length alone. */
 template <class Blk>

@@ -987,6 +987,7 @@ static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint
     return ZAMD_OK;
 }
 
+__global__ void k_fast(ZkJob J);
 static void tm_begin(zamd_engine *e, hipStream_t s, int which, int *slot)
 {
     *slot = -1;
@@ -1007,8 +1008,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     ZcParams P;
     int rc = fill_params(P, level, strategy, mem_level, chunk_size);
     if (rc) return rc;
-    if (P.parser == ZC_PARSE_FAST) {
-        fprintf(stderr, "zamd: levels 1-3 (deflate_fast) are not implemented on the GPU yet\n");
+    if (P.parser == ZC_PARSE_FAST && P.hash_bits > 15) {
+        fprintf(stderr, "zamd: levels 1-3 with memLevel 9 are not supported (the head table does not fit the LDS)\n");
         return ZAMD_STREAM_ERROR;
     }
     out_cap &= ~15ull;
@@ -1075,7 +1076,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             tm_end(e, s, slot);
         }
         tm_begin(e, s, 2, &slot);
-        if (P.parser == ZC_PARSE_SLOW && !getenv("ZAMD_SERIAL_PARSE")) {
+        if (P.parser == ZC_PARSE_FAST) hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
+        else if (P.parser == ZC_PARSE_SLOW && !getenv("ZAMD_SERIAL_PARSE")) {
             const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
             hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
             hipLaunchKernelGGL(k_hop, dim3(J.nchunks), dim3(64), 0, s, J);
@@ -1215,6 +1217,7 @@ extern "C" int zamd_crc32_dev(zamd_engine *e, uint32_t crc, const void *d_in, ui
 { return whole_checksum(e, d_in, n, 1, crc, result); }
 
 #include "zamd_inflate_impl.h"
+#include "zamd_fast_impl.h"
 
 /* ------------------------------------------------------------------ device-memory helpers */
 extern "C" int zamd_dev_alloc(zamd_engine *e, uint64_t bytes, void **d_ptr)
