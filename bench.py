@@ -28,6 +28,7 @@ WORKLOADS = {
     "l6_mixed": (4, 5, 6, 0, 8),      # BASELINE configs[2], the metric's "deflate GB/s @level 6"
     "l9_lowent": (2, 3, 9, 0, 8),     # configs[3]
     "l6_text": (0, 1, 6, 0, 8),
+    "l1_text": (0, 1, 1, 0, 8),       # configs[1]: deflate_fast
 }
 
 
@@ -40,6 +41,7 @@ def main():
     ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("ZAMD_BENCH_CHUNKS", "8192")))
     ap.add_argument("--cpu-sample-mib", type=int, default=int(os.environ.get("ZAMD_BENCH_CPU_MIB", "384")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inflate", action="store_true", help="skip the batch-inflate leg (reported beside the deflate value)")
     args = ap.parse_args()
 
     import torch
@@ -118,7 +120,8 @@ def main():
     # kernel timing of the last call (HIP events on the engine's own streams)
     names = ["chain", "match", "parse", "plan", "layout", "emit", "call"]
     kt = {nm: eng.timing_ms(i) for i, nm in enumerate(names)}
-    match_ms, match_launches = kt["match"]
+    dominant = "match" if kt["match"][1] else "parse"     # levels 1-3 have no separate match kernel
+    match_ms, match_launches = kt[dominant]
     ratio = n / max(1, total)
     roofline = None
     if match_launches:
@@ -134,10 +137,39 @@ def main():
             traffic = round(per_byte * (n / match_launches) / 1e9, 3)
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": "k_match", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_match" if dominant == "match" else "k_fast", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_unit": "GB per launch",
                     "algorithmic_gb_per_launch": round(alg_bytes / 1e9, 3),
                     "avg_launch_ms": round(avg_ms, 3), "launches": match_launches}
+
+    # ---- inflate leg of the metric (outside the timed deflate region): every rank inflates the shard it
+    # just produced, chunk-indexed, window of its first chunk = the 32 KiB in front of the shard
+    inflate = None
+    if not args.no_inflate:
+        d_back = torch.empty(n, dtype=torch.uint8, device="cuda")
+        def inf_step():
+            eng.inflate_dev(d_out.data_ptr(), d_off.data_ptr(), nchunks, d_back.data_ptr(), n, chunk_size=CHUNK,
+                            comp_bytes=int(total), d_head_window=d_buf.data_ptr() if head else 0)
+        inf_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            inf_step()
+        fence()
+        inf_elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([inf_elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            inf_elapsed = float(t.item())
+        ok = bool(torch.equal(d_back, d_buf[32768:]))
+        dec_ms, dec_n = eng.timing_ms(7)
+        res_ms, _ = eng.timing_ms(8)
+        inf_s = inf_elapsed / max(1, args.steps)
+        inflate = {"value": round(n * world / inf_s / 1e9, 4), "unit": "GB/s of inflated output", "ms_per_step": round(1e3 * inf_s, 3),
+                   "verified_equal_to_input": ok, "decode_ms": round(dec_ms, 3), "resolve_ms": round(res_ms, 3),
+                   "roofline": {"bound": "hbm", "kernel": "k_inf_decode", "achieved": round((n + total) / (dec_ms * 1e-3) / 1e9, 3) if dec_ms else None,
+                                "peak": 8000.0, "unit": "GB/s", "frac": round((n + total) / (dec_ms * 1e-3) / 1e9 / 8000.0, 6) if dec_ms else None}}
+        del d_back
 
     if rank == 0:
         # cheap self-check outside the timed region: the first chunks inflate to the input
@@ -159,7 +191,11 @@ def main():
                 cpu = {"value": round(r["bytes"] / r["seconds"] / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": r["kind"],
                        "sample": "first %d MiB of the same corpus, same chunk recipe, reference zlib %s built from source, one chunk per task"
                                  % (args.cpu_sample_mib, r["zlib"]),
-                       "ratio": round(r["bytes"] / r["out_bytes"], 4)}
+                       "ratio": round(r["bytes"] / r["out_bytes"], 4),
+                       "inflate_value": round(r["bytes"] / r["inflate_seconds"] / 1e9, 4) if r.get("inflate_seconds") else None,
+                       "single_stream_ratio": round(r["single_bytes"] / r["single_out"], 5) if r.get("single_out") else None,
+                       "chunked_ratio_same_prefix": round(r["single_bytes"] / r["chunked_out_same_prefix"], 5) if r.get("chunked_out_same_prefix") else None,
+                       "ratio_delta_vs_ref": round(r["single_out"] / r["chunked_out_same_prefix"] - 1.0, 6) if r.get("chunked_out_same_prefix") else None}
             except Exception as ex:          # the baseline is reported, never required
                 cpu = {"value": None, "unit": "GB/s", "cores": cores, "kind": "reference", "sample": "failed: %r" % (ex,)}
 
@@ -175,6 +211,7 @@ def main():
             "ratio": round(ratio, 4), "out_bytes_rank0": int(total), "out_bytes_all": int(gtotal),
             "kernel_ms_last_step": {k: round(v[0], 3) for k, v in kt.items()},
             "corpus_gen_s": round(gen_s, 2),
+            "inflate": inflate,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
