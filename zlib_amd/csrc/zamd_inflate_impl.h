@@ -431,38 +431,47 @@ __device__ __forceinline__ uint8_t zi_window_byte(const ZiSeg &S, uint32_t marke
     return head[32768 + q];
 }
 
-/* Last 32 KiB of every segment: plain bytes are written out, markers counted. */
-__global__ __launch_bounds__(1024) void k_inf_tail_pre(const ZiSeg *segs, const uint16_t *out16, uint8_t *out8, uint32_t *marks)
+/* Last 32 KiB of every segment: plain bytes are written out, markers are
+ * collected per segment as (offset in the tail) | (window index << 16). */
+__global__ __launch_bounds__(1024) void k_inf_tail_pre(const ZiSeg *segs, const uint16_t *out16, uint8_t *out8, uint32_t *marks, uint32_t *mlist)
 {
     const uint32_t si = blockIdx.x >> 5, part = blockIdx.x & 31u;
     const ZiSeg S = segs[si];
     const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
     const uint64_t e = (uint64_t)part * 1024 + threadIdx.x;
-    uint32_t mk = 0;
+    uint32_t mk = 0, v = 0;
     if (e < tl) {
         const uint64_t p = S.out_off + S.out_len - tl + e;
-        const uint16_t v = out16[p];
+        v = out16[p];
         if (v < ZI_MARK) out8[p] = (uint8_t)v; else mk = 1;
     }
-    uint64_t b = __ballot(mk);
-    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(&marks[si], (uint32_t)__popcll(b));
+    const uint64_t b = __ballot(mk);
+    if (b) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&marks[si], (uint32_t)__popcll(b));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (mk) mlist[(uint64_t)si * 32768u + base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)e | ((v - ZI_MARK) << 16);
+    }
 }
 
 /* Markers inside those tails, in stream order: each needs the (already resolved)
- * tail in front of it. */
-__global__ __launch_bounds__(1024) void k_inf_tail_serial(const ZiSeg *segs, uint64_t nseg, const uint16_t *out16, uint8_t *out8,
-                                                          const uint32_t *marks, const uint8_t *head)
+ * tail in front of it.  One workgroup walks the segments; only the collected
+ * markers are touched. */
+__global__ __launch_bounds__(1024) void k_inf_tail_serial(const ZiSeg *segs, uint64_t nseg, uint8_t *out8,
+                                                          const uint32_t *marks, const uint32_t *mlist, const uint8_t *head)
 {
     for (uint64_t si = 0; si < nseg; si++) {
-        if (marks[si] == 0) continue;
+        const uint32_t cnt = marks[si];
+        if (cnt == 0) continue;
         const ZiSeg S = segs[si];
         const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
-        for (uint64_t e = threadIdx.x; e < tl; e += 1024) {
-            const uint64_t p = S.out_off + S.out_len - tl + e;
-            const uint16_t v = out16[p];
-            if (v >= ZI_MARK) out8[p] = zi_window_byte(S, v, out8, head);
+        const uint64_t t0 = S.out_off + S.out_len - tl;
+        for (uint32_t k = threadIdx.x; k < cnt; k += 1024) {
+            const uint32_t m = mlist[si * 32768u + k];
+            out8[t0 + (m & 0xffffu)] = zi_window_byte(S, ZI_MARK + (m >> 16), out8, head);
         }
-        __threadfence();
+        __threadfence_block();      /* one workgroup, one CU: its L1 sees its own stores */
         __syncthreads();
     }
 }
@@ -511,9 +520,9 @@ __global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t n
 
 /* ------------------------------------------------------------------ host side */
 struct ZiState {
-    ZiSeg *d_segs = nullptr; uint64_t seg_cap = 0;
+    ZiSeg *d_segs = nullptr; uint64_t seg_cap = 0, mlist_cap = 0;
     uint16_t *d_stage = nullptr; uint64_t stage_cap = 0;     /* elements */
-    uint32_t *d_marks = nullptr; uint64_t marks_cap = 0;
+    uint32_t *d_marks = nullptr; uint32_t *d_mlist = nullptr;
     unsigned long long *d_res = nullptr;
     uint32_t last_status = 0; int64_t last_seg = -1;
 };
@@ -522,11 +531,11 @@ static void zi_free(zamd_engine *e)
 {
     ZiState *z = e->inf;
     if (!z) return;
-    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_res);
+    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res);
     delete z; e->inf = nullptr;
 }
 
-static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems)
+static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems, bool resolve)
 {
     if (!e->inf) { e->inf = new (std::nothrow) ZiState(); if (!e->inf) return ZAMD_MEM_ERROR; }
     ZiState *z = e->inf;
@@ -537,6 +546,11 @@ static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems)
         if (hipMalloc((void **)&z->d_segs, want * sizeof(ZiSeg)) != hipSuccess) return ZAMD_MEM_ERROR;
         if (hipMalloc((void **)&z->d_marks, want * 4) != hipSuccess) return ZAMD_MEM_ERROR;
         z->seg_cap = want;
+    }
+    if (resolve && z->mlist_cap < nseg) {     /* marker lists: 32 Ki entries per segment */
+        hipFree(z->d_mlist); z->d_mlist = nullptr; z->mlist_cap = 0;
+        if (hipMalloc((void **)&z->d_mlist, nseg * 32768ull * 4) != hipSuccess) return ZAMD_MEM_ERROR;
+        z->mlist_cap = nseg;
     }
     if (z->stage_cap < stage_elems) {
         hipFree(z->d_stage); z->d_stage = nullptr; z->stage_cap = 0;
@@ -576,8 +590,8 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
     if (d_out && rc == ZAMD_OK && out_bytes) {
         tm_begin(e, s, 8, &slot);
         HIPCHK(hipMemsetAsync(z->d_marks, 0, nseg * 4, s));
-        hipLaunchKernelGGL(k_inf_tail_pre, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (uint8_t *)d_out, z->d_marks);
-        hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, z->d_stage, (uint8_t *)d_out, z->d_marks, (const uint8_t *)d_head);
+        hipLaunchKernelGGL(k_inf_tail_pre, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (uint8_t *)d_out, z->d_marks, z->d_mlist);
+        hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, (uint8_t *)d_out, z->d_marks, z->d_mlist, (const uint8_t *)d_head);
         uint64_t groups = (out_bytes + 2047) / 2048;
         hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, chunk_size, z->d_stage, (uint8_t *)d_out, (const uint8_t *)d_head, out_bytes);
         tm_end(e, s, slot);
@@ -597,7 +611,7 @@ extern "C" int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64
     if (n_chunks == 0 || n_chunks > 0x7fffffffull / 32) return ZAMD_STREAM_ERROR;
     if ((n_out + chunk_size - 1) / chunk_size > n_chunks) return ZAMD_STREAM_ERROR;
     HIPCHK(hipSetDevice(e->device));
-    int rc = zi_ensure(e, n_chunks, n_chunks * (uint64_t)chunk_size);
+    int rc = zi_ensure(e, n_chunks, n_chunks * (uint64_t)chunk_size, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_inf_setup, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, e->st[0], d_chunk_off, n_chunks, chunk_size, n_out,
                        d_head_window ? 32768u : 0u, e->inf->d_segs);
@@ -632,7 +646,7 @@ extern "C" int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uin
         segs[i].status = 0xffffffffu;
     }
     HIPCHK(hipSetDevice(e->device));
-    int rc = zi_ensure(e, nseg, need);
+    int rc = zi_ensure(e, nseg, need, d_out != nullptr);
     if (rc) return rc;
     HIPCHK(hipMemcpy(e->inf->d_segs, segs, nseg * sizeof(ZiSeg), hipMemcpyHostToDevice));
     /* every segment is reported, so a failing one is not an error of the call */
