@@ -67,13 +67,41 @@ struct ZiSeg {
     uint32_t status, final_seen;
 };
 
+/* Table entry: bits 0-3 code length (0 = no code this short), 4-7 number of extra
+ * bits, 8-9 kind, 16-31 value.  Literal/length code: kind 0 literal (value =
+ * byte), 1 length (value = base length), 2 end of block, 3 invalid symbol.
+ * Distance code: kind 0 (value = base distance) or 3.  Code-length code: value =
+ * symbol. */
+#define ZI_K_LIT 0u
+#define ZI_K_LEN 1u
+#define ZI_K_EOB 2u
+#define ZI_K_BAD 3u
+enum { ZI_T_C = 0, ZI_T_L = 1, ZI_T_D = 2 };
+
+__device__ __forceinline__ uint32_t zi_entry(uint32_t table, uint32_t sym, uint32_t len)
+{
+    if (table == ZI_T_L) {
+        if (sym < 256) return len | (ZI_K_LIT << 8) | (sym << 16);
+        if (sym == 256) return len | (ZI_K_EOB << 8);
+        if (sym > 285) return len | (ZI_K_BAD << 8);
+        const uint32_t lc = sym - 257u;
+        return len | (zc_len_extra(lc) << 4) | (ZI_K_LEN << 8) | ((zc_len_base(lc) + 3u) << 16);
+    }
+    if (table == ZI_T_D) {
+        if (sym >= 30) return len | (ZI_K_BAD << 8);
+        return len | (zc_dist_extra(sym) << 4) | ((zc_dist_base(sym) + 1u) << 16);
+    }
+    return len | (sym << 16);
+}
+
 struct ZiTab {                 /* one canonical code: first-level table + search arrays */
-    uint16_t *lut, *sorted;
+    uint32_t *lut; uint16_t *sorted;
     uint16_t *first, *cnt, *off;   /* indexed by code length 1..15 */
+    uint32_t table;
 };
 
 struct ZiLds {
-    uint16_t lut_l[1u << ZI_ROOT_L], lut_d[1u << ZI_ROOT_D], lut_c[1u << ZI_ROOT_C];
+    uint32_t lut_l[1u << ZI_ROOT_L], lut_d[1u << ZI_ROOT_D], lut_c[1u << ZI_ROOT_C];
     uint16_t sorted_l[288], sorted_d[32], sorted_c[20];
     uint16_t meta[3][3][16];
     uint32_t cntw[16];
@@ -120,6 +148,60 @@ __device__ __forceinline__ uint64_t zi_peek(ZiBits &b, uint32_t lane)
 
 __device__ __forceinline__ uint32_t zi_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+/* Inclusive prefix sum over the 64 lanes with DPP row shifts and broadcasts (no LDS). */
+__device__ __forceinline__ uint32_t zi_scan_incl(uint32_t v)
+{
+    uint32_t s = v;
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);    /* row_shr:3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, true);    /* row_shr:4, banks 1-3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, true);    /* row_shr:8, banks 2-3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, true);    /* row_bcast:15 into rows 1, 3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, true);    /* row_bcast:31 into rows 2, 3 */
+    return s;
+}
+
+/* Lane l decodes the token that would start l bits behind bit position sb:
+ * tlen = its length in bits (bits 0-7) with a note in bits 8+ (1 = end of block,
+ * 2 = leave it to the one-token-at-a-time path: long code or invalid symbol),
+ * word = the parked-symbol word.  Only lanes on the true token chain matter. */
+#define ZI_SP_EOB    1u
+#define ZI_SP_SCALAR 2u
+__device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, const uint32_t *lut_l, const uint32_t *lut_d,
+                                        uint32_t &tlen, uint32_t &word)
+{
+    b.bitpos = sb;
+    (void)zi_peek(b, lane);                              /* brings the window up to sb */
+    const uint32_t d0 = (uint32_t)((sb >> 5) - b.wbase);  /* 0..63 */
+    uint32_t D[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint32_t a = __builtin_amdgcn_readlane(b.cur, (d0 + i) & 63u), c = __builtin_amdgcn_readlane(b.nxt, (d0 + i) & 63u);
+        D[i] = d0 + i < 64 ? a : c;
+    }
+    const uint32_t t = ((uint32_t)sb & 31u) + lane, kk = t >> 5, sh = t & 31u;
+    const uint32_t A = kk == 0 ? D[0] : kk == 1 ? D[1] : D[2];
+    const uint32_t Bv = kk == 0 ? D[1] : kk == 1 ? D[2] : D[3];
+    const uint32_t C = kk == 0 ? D[2] : kk == 1 ? D[3] : D[4];
+    const uint32_t lo = __builtin_amdgcn_alignbit(Bv, A, sh), hi = __builtin_amdgcn_alignbit(C, Bv, sh);
+    const uint64_t W = ((uint64_t)hi << 32) | lo;
+    const uint32_t e1 = lut_l[lo & ((1u << ZI_ROOT_L) - 1u)];
+    const uint32_t l1 = e1 & 15u, lx = (e1 >> 4) & 15u, k1 = (e1 >> 8) & 3u, v1 = e1 >> 16;
+    const uint32_t o2 = l1 + lx;
+    const uint32_t mlen = v1 + ((lo >> l1) & ((1u << lx) - 1u));
+    const uint32_t e2 = lut_d[(lo >> o2) & ((1u << ZI_ROOT_D) - 1u)];
+    const uint32_t l2 = e2 & 15u, dx = (e2 >> 4) & 15u, k2 = (e2 >> 8) & 3u, v2 = e2 >> 16;
+    const uint32_t o3 = o2 + l2;
+    const uint32_t dist = v2 + ((uint32_t)(W >> o3) & ((1u << dx) - 1u));
+    const bool islen = k1 == ZI_K_LEN;
+    const bool scalar = l1 == 0 || k1 == ZI_K_BAD || (islen && (l2 == 0 || k2 == ZI_K_BAD));
+    tlen = islen ? o3 + dx : l1;
+    word = islen ? (0x80000000u | ((mlen - 3u) << 16) | dist) : v1;
+    if (k1 == ZI_K_EOB) tlen |= ZI_SP_EOB << 8;
+    if (scalar) tlen = ZI_SP_SCALAR << 8;
+}
+
 /* Builds the tables of one code from lens[0..n).  Returns 0 = complete, 1 =
  * over-subscribed, 2 = incomplete; *maxlen = longest code (0 = no codes).
  * (Validity rules: inftrees.c:107-138.) */
@@ -165,24 +247,24 @@ __device__ uint32_t zi_build(ZiLds &L, const uint8_t *lens, uint32_t n, uint32_t
         uint32_t lim = mx < root ? mx : root;
         for (uint32_t l = 1; l <= lim; l++) {
             uint32_t d = (rev >> (root - l)) - T.first[l];
-            if (d < T.cnt[l]) { e = ((uint32_t)T.sorted[T.off[l] + d] << 4) | l; break; }
+            if (d < T.cnt[l]) { e = zi_entry(T.table, T.sorted[T.off[l] + d], l); break; }
         }
-        T.lut[i] = (uint16_t)e;
+        T.lut[i] = e;
     }
     __syncthreads();
     return left > 0 ? 2u : 0u;
 }
 
-/* Code longer than the first-level table: canonical search.  Returns symbol |
- * length << 16, or 0xffffffff when no code matches. */
+/* Code longer than the first-level table: canonical search.  Returns the table
+ * entry, or 0 when no code matches. */
 __device__ __forceinline__ uint32_t zi_slow(const ZiTab &T, uint32_t bits, uint32_t root)
 {
     uint32_t rev = __brev(bits) >> 17;                   /* first 15 stream bits, first bit on top */
     for (uint32_t l = root + 1; l <= 15; l++) {
         uint32_t d = (rev >> (15 - l)) - zi_uni(T.first[l]);
-        if (d < zi_uni(T.cnt[l])) return zi_uni(T.sorted[zi_uni(T.off[l]) + d]) | (l << 16);
+        if (d < zi_uni(T.cnt[l])) return zi_entry(T.table, zi_uni(T.sorted[zi_uni(T.off[l]) + d]), l);
     }
-    return 0xffffffffu;
+    return 0u;
 }
 
 template <bool WRITE>
@@ -196,9 +278,9 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
     const uint64_t end_bits = S.in_end_bit;
     ZiBits B;
     zi_bits_init(B, (const uint32_t *)comp, (comp_bytes + 3) >> 2, S.in_bit, lane);
-    ZiTab TL{L.lut_l, L.sorted_l, L.meta[0][0], L.meta[0][1], L.meta[0][2]};
-    ZiTab TD{L.lut_d, L.sorted_d, L.meta[1][0], L.meta[1][1], L.meta[1][2]};
-    ZiTab TC{L.lut_c, L.sorted_c, L.meta[2][0], L.meta[2][1], L.meta[2][2]};
+    ZiTab TL{L.lut_l, L.sorted_l, L.meta[0][0], L.meta[0][1], L.meta[0][2], ZI_T_L};
+    ZiTab TD{L.lut_d, L.sorted_d, L.meta[1][0], L.meta[1][1], L.meta[1][2], ZI_T_D};
+    ZiTab TC{L.lut_c, L.sorted_c, L.meta[2][0], L.meta[2][1], L.meta[2][2], ZI_T_C};
     uint16_t *dst = out16 + S.out_off;
 
     uint64_t pos = 0;                  /* elements produced so far */
@@ -215,8 +297,7 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
         const uint32_t w = mysym;
         const bool ism = valid && (w >> 31);
         const uint32_t len = valid ? (ism ? ((w >> 16) & 0xffu) + 3u : 1u) : 0u;
-        uint32_t incl = len;
-        for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(incl, d); if ((int)lane >= d) incl += t; }
+        const uint32_t incl = zi_scan_incl(len);
         const uint32_t off = incl - len;
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
         /* distance checks (inflate.c:1145-1158) */
@@ -309,7 +390,7 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
                 while (idx < total) {
                     bits = zi_peek(B, lane);
                     uint32_t e = zi_uni(L.lut_c[(uint32_t)bits & 127u]);
-                    uint32_t l = e & 15u, sym = e >> 4;
+                    uint32_t l = e & 15u, sym = e >> 16;
                     if (l == 0) { l = 1; sym = 0; }                          /* empty code: inftrees.c:118-125 */
                     bits >>= l; B.bitpos += l;
                     if (sym < 16) {
@@ -344,45 +425,56 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
                 r = zi_build(L, L.lens + 288, ndist, ZI_ROOT_D, TD, lane, &mx);
                 if (r == 1 || (r == 2 && mx > 1)) { fail(ZI_ERR_DSET, 0); break; }
             }
-            /* ---- symbols of the block */
-            bool bad = false;
-            for (;;) {
-                bits = zi_peek(B, lane);
-                uint32_t e = zi_uni(L.lut_l[(uint32_t)bits & ((1u << ZI_ROOT_L) - 1u)]);
-                uint32_t l = e & 15u, sym = e >> 4;
-                if (l == 0) {
-                    uint32_t r = zi_slow(TL, (uint32_t)bits, ZI_ROOT_L);
-                    if (r == 0xffffffffu) { fail(ZI_ERR_LCODE, 1); bad = true; break; }
-                    sym = r & 0xffffu; l = r >> 16;
-                }
-                B.bitpos += l;
-                uint32_t word;
-                if (sym < 256) word = sym;
-                else if (sym == 256) break;
-                else {
-                    if (sym > 285) { fail(ZI_ERR_LCODE, 0); bad = true; break; }
-                    bits >>= l;
-                    const uint32_t lc = sym - 257u, lx = zc_len_extra(lc);
-                    const uint32_t mlen = zc_len_base(lc) + ((uint32_t)bits & ((1u << lx) - 1u));   /* length - 3 */
-                    B.bitpos += lx;
-                    bits = zi_peek(B, lane);
-                    e = zi_uni(L.lut_d[(uint32_t)bits & ((1u << ZI_ROOT_D) - 1u)]);
-                    l = e & 15u;
-                    uint32_t ds = e >> 4;
-                    if (l == 0) {
-                        uint32_t r = zi_slow(TD, (uint32_t)bits, ZI_ROOT_D);
-                        if (r == 0xffffffffu) { fail(ZI_ERR_DCODE, 1); bad = true; break; }
-                        ds = r & 0xffffu; l = r >> 16;
+            /* ---- symbols of the block: 64 bit offsets are decoded at once, then the
+             * chain of real tokens is followed through the lanes' results */
+            bool bad = false, eob = false;
+            uint64_t sb = B.bitpos;
+            uint32_t sp = 0;                      /* offset of the next token inside the span */
+            while (!eob && !bad) {
+                uint32_t tl, wd;
+                zi_span(B, sb, lane, L.lut_l, L.lut_d, tl, wd);
+                bool restart = false;
+                while (sp < 64) {
+                    const uint32_t t = __builtin_amdgcn_readlane(tl, sp), w = __builtin_amdgcn_readlane(wd, sp);
+                    if (t < 256u) {
+                        mysym = lane == k ? w : mysym;
+                        sp += t;
+                        if (++k == 64) { B.bitpos = sb + sp; if (!flush()) { bad = true; break; } }
+                        continue;
                     }
-                    if (ds >= 30) { B.bitpos += l; fail(ZI_ERR_DCODE, 0); bad = true; break; }
-                    bits >>= l;
-                    const uint32_t dx = zc_dist_extra(ds);
-                    const uint32_t dist = 1u + zc_dist_base(ds) + ((uint32_t)bits & ((1u << dx) - 1u));
-                    B.bitpos += l + dx;
-                    word = 0x80000000u | (mlen << 16) | dist;
+                    B.bitpos = sb + sp;
+                    if ((t >> 8) == ZI_SP_EOB) { B.bitpos += t & 0xffu; eob = true; break; }
+                    /* one token the long way: codes beyond the first-level tables, invalid symbols */
+                    bits = zi_peek(B, lane);
+                    uint32_t e = zi_uni(L.lut_l[(uint32_t)bits & ((1u << ZI_ROOT_L) - 1u)]);
+                    if ((e & 15u) == 0) e = zi_slow(TL, (uint32_t)bits, ZI_ROOT_L);
+                    if (e == 0) { fail(ZI_ERR_LCODE, 1); bad = true; break; }
+                    uint32_t l = e & 15u, kd = (e >> 8) & 3u;
+                    B.bitpos += l;
+                    if (kd == ZI_K_BAD) { fail(ZI_ERR_LCODE, 0); bad = true; break; }
+                    if (kd == ZI_K_EOB) { eob = true; break; }
+                    uint32_t word = e >> 16;
+                    if (kd == ZI_K_LEN) {
+                        const uint32_t lx = (e >> 4) & 15u;
+                        const uint32_t mlen = (e >> 16) + ((uint32_t)(bits >> l) & ((1u << lx) - 1u));
+                        B.bitpos += lx;
+                        bits = zi_peek(B, lane);
+                        e = zi_uni(L.lut_d[(uint32_t)bits & ((1u << ZI_ROOT_D) - 1u)]);
+                        if ((e & 15u) == 0) e = zi_slow(TD, (uint32_t)bits, ZI_ROOT_D);
+                        if (e == 0) { fail(ZI_ERR_DCODE, 1); bad = true; break; }
+                        l = e & 15u;
+                        if (((e >> 8) & 3u) == ZI_K_BAD) { B.bitpos += l; fail(ZI_ERR_DCODE, 0); bad = true; break; }
+                        const uint32_t dx = (e >> 4) & 15u;
+                        const uint32_t dist = (e >> 16) + ((uint32_t)(bits >> l) & ((1u << dx) - 1u));
+                        B.bitpos += l + dx;
+                        word = 0x80000000u | ((mlen - 3u) << 16) | dist;
+                    }
+                    mysym = lane == k ? word : mysym;
+                    if (++k == 64) { if (!flush()) { bad = true; break; } }
+                    sb = B.bitpos; sp = 0; restart = true;
+                    break;
                 }
-                mysym = lane == k ? word : mysym;
-                if (++k == 64) { if (!flush()) { bad = true; break; } }
+                if (!restart) { sb += 64; sp -= 64; }
             }
             if (bad) break;
         }
@@ -615,6 +707,7 @@ extern "C" int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64
     if (rc) return rc;
     hipLaunchKernelGGL(k_inf_setup, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, e->st[0], d_chunk_off, n_chunks, chunk_size, n_out,
                        d_head_window ? 32768u : 0u, e->inf->d_segs);
+    if (getenv("ZAMD_INF_COUNTONLY")) d_out = nullptr;      /* diagnostic: decode without writing */
     return zi_run(e, d_comp, comp_bytes, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk);
 }
 
