@@ -148,6 +148,14 @@ __device__ __forceinline__ uint64_t zi_peek(ZiBits &b, uint32_t lane)
 
 __device__ __forceinline__ uint32_t zi_uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+/* v with lane `sel` replaced by the wave-uniform value x.  Two vector
+ * instructions on purpose: the scalar unit, shared by the four SIMDs of a CU, is
+ * the scarce resource of the decoder. */
+__device__ __forceinline__ uint32_t zi_writelane(uint32_t v, uint32_t x, uint32_t sel)
+{
+    return (threadIdx.x == sel) ? x : v;
+}
+
 /* Inclusive prefix sum over the 64 lanes with DPP row shifts and broadcasts (no LDS). */
 __device__ __forceinline__ uint32_t zi_scan_incl(uint32_t v)
 {
@@ -434,14 +442,20 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
                 uint32_t tl, wd;
                 zi_span(B, sb, lane, L.lut_l, L.lut_d, tl, wd);
                 bool restart = false;
-                while (sp < 64) {
-                    const uint32_t t = __builtin_amdgcn_readlane(tl, sp), w = __builtin_amdgcn_readlane(wd, sp);
-                    if (t < 256u) {
-                        mysym = lane == k ? w : mysym;
-                        sp += t;
-                        if (++k == 64) { B.bitpos = sb + sp; if (!flush()) { bad = true; break; } }
-                        continue;
+                for (;;) {
+                    /* the hot loop: nothing but ordinary tokens */
+                    uint32_t t = 0;
+                    if (sp < 64) {
+                        do {
+                            t = __builtin_amdgcn_readlane(tl, sp);
+                            const uint32_t w = __builtin_amdgcn_readlane(wd, sp);
+                            if (t >= 256u) break;
+                            mysym = zi_writelane(mysym, w, k);
+                            sp += t; k++;
+                        } while ((sp | k) < 64u);       /* both below 64 */
                     }
+                    if (k == 64) { B.bitpos = sb + sp; if (!flush()) { bad = true; break; } continue; }
+                    if (sp >= 64) break;
                     B.bitpos = sb + sp;
                     if ((t >> 8) == ZI_SP_EOB) { B.bitpos += t & 0xffu; eob = true; break; }
                     /* one token the long way: codes beyond the first-level tables, invalid symbols */
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
                         B.bitpos += l + dx;
                         word = 0x80000000u | ((mlen - 3u) << 16) | dist;
                     }
-                    mysym = lane == k ? word : mysym;
+                    mysym = zi_writelane(mysym, word, k);
                     if (++k == 64) { if (!flush()) { bad = true; break; } }
                     sb = B.bitpos; sp = 0; restart = true;
                     break;
