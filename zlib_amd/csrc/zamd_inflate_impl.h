@@ -28,6 +28,8 @@
 #define ZI_ROOT_D 8
 #define ZI_ROOT_C 7
 #define ZI_MARK   256u       /* first marker value: byte 0 of the preceding 32 KiB */
+#define ZI_STAGE  1024u      /* elements of the per-wave output stage (>= 258) */
+#define ZI_EMPTY  0xffffu    /* stage element not produced yet (no byte or marker has this value) */
 __constant__ uint8_t zi_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   /* inflate.c:608-609 */
 
 enum {
@@ -107,6 +109,7 @@ struct ZiLds {
     uint32_t cntw[16];
     uint8_t lens[320 + 8];
     uint8_t cl[20 + 4];
+    uint16_t stage[ZI_STAGE];      /* output of the tokens being written, before it goes to memory */
 };
 
 struct ZiBits {
@@ -313,25 +316,75 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
         if (__ballot(far)) { status = ZI_ERR_FAR; return false; }
         if (pos + total > S.out_cap) { status = ZI_ERR_OUTCAP; return false; }
         if (WRITE) {
-            if (valid && !ism) dst[pos + off] = (uint16_t)w;
-            uint64_t mm = __ballot(ism);
-            while (mm) {
-                const uint32_t m = (uint32_t)__builtin_ctzll(mm);
-                mm &= mm - 1;
-                const uint32_t wm = __builtin_amdgcn_readlane(w, m);
-                const uint32_t om = __builtin_amdgcn_readlane(off, m);
-                const uint32_t ml = ((wm >> 16) & 0xffu) + 3u, md = wm & 0xffffu;
-                const int64_t d0 = (int64_t)(pos + om), s0 = d0 - (int64_t)md;
-                if (s0 + (int64_t)ml > (int64_t)pos) __threadfence_block();   /* reads what this batch wrote */
-                for (uint32_t j = lane; j < ml; j += 64) {
-                    const int64_t sj = s0 + (int64_t)(md >= ml ? j : j % md);
-                    uint16_t v;
-                    if (sj < 0) v = (uint16_t)(ZI_MARK + 32768 + sj);
-                    else v = dst[sj];
-                    dst[d0 + j] = v;
+            /* Every lane writes its own token.  The tokens of a sub-batch (at most
+             * ZI_STAGE elements) are assembled in LDS: a copy whose source lies inside
+             * the sub-batch waits, element by element, until the owner has produced it
+             * (sources lie strictly below their destinations, so the lowest unfinished
+             * element can always advance); sources below the sub-batch come from
+             * memory, four elements at a time, or are window markers. */
+            uint32_t done_tok = 0, base_off = 0;
+            while (done_tok < k) {
+                const bool in = valid && lane >= done_tok && (incl - base_off) <= ZI_STAGE;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(in));
+                const uint32_t sub_total = __builtin_amdgcn_readlane(incl, done_tok + cnt - 1) - base_off;
+                for (uint32_t j = lane; j < sub_total; j += 64) L.stage[j] = (uint16_t)ZI_EMPTY;
+                const uint32_t o = off - base_off;
+                const int64_t bs = (int64_t)(pos + base_off);          /* position of stage[0] in the segment */
+                const int32_t sr = (int32_t)o - (int32_t)(w & 0xffffu);
+                uint32_t rem = (in && ism) ? len : 0u, j = 0;
+                if (in && !ism) L.stage[o] = (uint16_t)w;
+                /* long or self-overlapping copies are done by all lanes together, each when
+                 * it is the lowest unfinished token (everything below it is complete then) */
+                const bool mycoop = rem != 0 && ((w & 0xffffu) < len || len > 32u);
+                const uint64_t coopm = __ballot(mycoop);
+                for (;;) {
+                    const uint64_t um = __ballot(rem != 0);
+                    if (um == 0) break;
+                    const uint32_t first = (uint32_t)__builtin_ctzll(um);
+                    if ((coopm >> first) & 1ull) {
+                        const uint32_t wc = __builtin_amdgcn_readlane(w, first), oc = __builtin_amdgcn_readlane(o, first);
+                        const uint32_t lc = ((wc >> 16) & 0xffu) + 3u, dc = wc & 0xffffu;
+                        const int32_t src = (int32_t)oc - (int32_t)dc;
+                        for (uint32_t jj = lane; jj < lc; jj += 64) {
+                            const int32_t sidx = src + (int32_t)(dc >= lc ? jj : jj % dc);
+                            uint32_t v;
+                            if (sidx < 0) { const int64_t a = bs + sidx; v = a < 0 ? (uint32_t)(ZI_MARK + 32768 + a) : (uint32_t)dst[a]; }
+                            else v = L.stage[sidx];
+                            L.stage[oc + jj] = (uint16_t)v;
+                        }
+                        if (lane == first) rem = 0;
+                        continue;
+                    }
+                    if (rem && !mycoop) {
+                        const int32_t sidx = sr + (int32_t)j;
+                        if (sidx + 3 < 0) {
+                            const int64_t a = bs + sidx;
+                            uint32_t v[4];
+                            if (a >= 0) {
+                                uint64_t x;
+                                __builtin_memcpy(&x, dst + a, 8);
+                                v[0] = (uint32_t)x & 0xffffu; v[1] = (uint32_t)(x >> 16) & 0xffffu;
+                                v[2] = (uint32_t)(x >> 32) & 0xffffu; v[3] = (uint32_t)(x >> 48);
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 4; i++) v[i] = (a + i < 0) ? (uint32_t)(ZI_MARK + 32768 + (a + i)) : (uint32_t)dst[a + i];
+                            }
+                            const uint32_t take = rem < 4u ? rem : 4u;
+#pragma unroll
+                            for (uint32_t i = 0; i < 4; i++) if (i < take) L.stage[o + j + i] = (uint16_t)v[i];
+                            j += take; rem -= take;
+                        } else {
+                            uint32_t v;
+                            if (sidx < 0) { const int64_t a = bs + sidx; v = a < 0 ? (uint32_t)(ZI_MARK + 32768 + a) : (uint32_t)dst[a]; }
+                            else v = L.stage[sidx];
+                            if (v != ZI_EMPTY) { L.stage[o + j] = (uint16_t)v; j++; rem--; }
+                        }
+                    }
                 }
+                for (uint32_t jj = lane; jj < sub_total; jj += 64) dst[bs + jj] = L.stage[jj];
+                __threadfence_block();                                 /* later sub-batches and batches read these */
+                done_tok += cnt; base_off += sub_total;
             }
-            __threadfence_block();
         }
         pos += total; k = 0;
         return true;
@@ -582,6 +635,42 @@ __global__ __launch_bounds__(1024) void k_inf_tail_serial(const ZiSeg *segs, uin
     }
 }
 
+/* The same by pointer jumping, for the regular case that every segment but the
+ * last is at least 32 KiB long (its tail IS the next segment's window): a tail
+ * element is a resolved byte (bit 31 set) or the slot of the window element it
+ * copies, segment * 32768 + index; every round replaces a pointer by what it
+ * points at, so chains that run back through s segments vanish in log2(s) rounds.
+ * In-place updates are safe: a slot always holds either its byte or a pointer
+ * to a slot that will hold the same byte. */
+__global__ __launch_bounds__(1024) void k_inf_ref_init(const ZiSeg *segs, const uint16_t *out16, const uint8_t *head, uint32_t *ref)
+{
+    const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
+    const ZiSeg S = segs[si];
+    const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
+    if (e >= tl) return;
+    const uint32_t v = out16[S.out_off + S.out_len - tl + e];
+    uint32_t r;
+    if (v < ZI_MARK) r = 0x80000000u | v;
+    else if (si == 0) r = 0x80000000u | head[v - ZI_MARK];
+    else r = (si - 1u) * 32768u + (v - ZI_MARK);
+    ref[(uint64_t)si * 32768u + e] = r;
+}
+__global__ __launch_bounds__(256) void k_inf_ref_jump(uint32_t *ref, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = ref[i];
+    if (!(r >> 31)) ref[i] = __hip_atomic_load(ref + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(1024) void k_inf_ref_write(const ZiSeg *segs, const uint32_t *ref, uint8_t *out8)
+{
+    const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
+    const ZiSeg S = segs[si];
+    const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
+    if (e >= tl) return;
+    out8[S.out_off + S.out_len - tl + e] = (uint8_t)ref[(uint64_t)si * 32768u + e];
+}
+
 /* Everything in front of the tails: 8 elements per thread. */
 __global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t nseg, uint32_t chunk_size, const uint16_t *out16,
                                                    uint8_t *out8, const uint8_t *head, uint64_t total)
@@ -669,7 +758,7 @@ static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems, bool r
 
 /* decode (+ resolve when d_out != NULL) the segments already in z->d_segs */
 static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint64_t nseg, uint32_t chunk_size,
-                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg)
+                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg, bool regular_tails)
 {
     ZiState *z = e->inf;
     hipStream_t s = e->st[0];
@@ -695,9 +784,19 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
     }
     if (d_out && rc == ZAMD_OK && out_bytes) {
         tm_begin(e, s, 8, &slot);
-        HIPCHK(hipMemsetAsync(z->d_marks, 0, nseg * 4, s));
-        hipLaunchKernelGGL(k_inf_tail_pre, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (uint8_t *)d_out, z->d_marks, z->d_mlist);
-        hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, (uint8_t *)d_out, z->d_marks, z->d_mlist, (const uint8_t *)d_head);
+        if (regular_tails && nseg < 65536 && !getenv("ZAMD_INF_SERIAL_TAILS")) {
+            const uint64_t nref = nseg * 32768ull;
+            hipLaunchKernelGGL(k_inf_ref_init, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (const uint8_t *)d_head, z->d_mlist);
+            uint32_t rounds = 1;
+            while ((1ull << rounds) < nseg) rounds++;
+            for (uint32_t r = 0; r <= rounds; r++)
+                hipLaunchKernelGGL(k_inf_ref_jump, dim3((uint32_t)((nref + 255) / 256)), dim3(256), 0, s, z->d_mlist, nref);
+            hipLaunchKernelGGL(k_inf_ref_write, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, (uint8_t *)d_out);
+        } else {
+            HIPCHK(hipMemsetAsync(z->d_marks, 0, nseg * 4, s));
+            hipLaunchKernelGGL(k_inf_tail_pre, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (uint8_t *)d_out, z->d_marks, z->d_mlist);
+            hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, (uint8_t *)d_out, z->d_marks, z->d_mlist, (const uint8_t *)d_head);
+        }
         uint64_t groups = (out_bytes + 2047) / 2048;
         hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, chunk_size, z->d_stage, (uint8_t *)d_out, (const uint8_t *)d_head, out_bytes);
         tm_end(e, s, slot);
@@ -722,7 +821,7 @@ extern "C" int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64
     hipLaunchKernelGGL(k_inf_setup, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, e->st[0], d_chunk_off, n_chunks, chunk_size, n_out,
                        d_head_window ? 32768u : 0u, e->inf->d_segs);
     if (getenv("ZAMD_INF_COUNTONLY")) d_out = nullptr;      /* diagnostic: decode without writing */
-    return zi_run(e, d_comp, comp_bytes, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk);
+    return zi_run(e, d_comp, comp_bytes, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk, chunk_size >= 32768);
 }
 
 extern "C" int zamd_inflate_dev(zamd_engine *e, const void *d_comp, const uint64_t *d_chunk_off, uint64_t n_chunks,
@@ -758,7 +857,10 @@ extern "C" int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uin
     HIPCHK(hipMemcpy(e->inf->d_segs, segs, nseg * sizeof(ZiSeg), hipMemcpyHostToDevice));
     /* every segment is reported, so a failing one is not an error of the call */
     int64_t bad = -1;
-    rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad);
+    bool regular = true;            /* every segment but the last at least 32 KiB long and back to back */
+    for (uint64_t i = 0; i + 1 < nseg && regular; i++)
+        regular = segs[i].out_cap >= 32768 && segs[i].out_off + segs[i].out_cap == segs[i + 1].out_off && (segs[i].mode & ZAMD_INF_EXACT);
+    rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad, regular);
     if (rc != ZAMD_OK && rc != ZAMD_DATA_ERROR) return rc;
     HIPCHK(hipMemcpy(segs, e->inf->d_segs, nseg * sizeof(ZiSeg), hipMemcpyDeviceToHost));
     return ZAMD_OK;
