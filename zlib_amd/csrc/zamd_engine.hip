@@ -853,13 +853,15 @@ struct ZeWorkspace {
     uint64_t pdist_len = 0;
 };
 
+#define ZE_STREAMS 8            /* batches in flight at most */
 struct ZiState;
 struct zamd_engine {
     int device;
     ZiState *inf;                 /* batch-inflate workspace, created on first use */
-    hipStream_t st[2];
-    hipEvent_t ev_scan[2];
-    ZeWorkspace ws[2];
+    hipStream_t st[ZE_STREAMS];
+    hipEvent_t ev_scan[ZE_STREAMS], ev_init;
+    ZeWorkspace ws[ZE_STREAMS];
+    int nstreams;
     uint64_t ws_budget;
     uint64_t *d_total; uint32_t *d_err;
     uint64_t *d_off_own; uint64_t d_off_cap;
@@ -921,14 +923,17 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     zamd_engine *e = new (std::nothrow) zamd_engine();
     if (!e) return ZAMD_MEM_ERROR;
     memset((void *)e, 0, sizeof *e);
-    for (int i = 0; i < 2; i++) e->ws[i] = ZeWorkspace();
+    for (int i = 0; i < ZE_STREAMS; i++) e->ws[i] = ZeWorkspace();
+    e->nstreams = 4;                 /* one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4) */
+    if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->device = device;
     e->ws_budget = workspace_bytes ? workspace_bytes : (48ull << 30);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < ZE_STREAMS; i++) {
         HIPCHK(hipStreamCreateWithFlags(&e->st[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&e->ev_scan[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreate(&e->ev_call[i]));
     }
+    HIPCHK(hipEventCreateWithFlags(&e->ev_init, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&e->ev_call[i]));
     HIPCHK(hipMalloc((void **)&e->d_total, 8));
     HIPCHK(hipMalloc((void **)&e->d_err, 4));
     crc_host_init();
@@ -946,7 +951,9 @@ extern "C" void zamd_engine_destroy(zamd_engine *e)
     hipSetDevice(e->device);
     hipDeviceSynchronize();
     zi_free(e);
-    for (int i = 0; i < 2; i++) { ws_free(e->ws[i]); hipStreamDestroy(e->st[i]); hipEventDestroy(e->ev_scan[i]); hipEventDestroy(e->ev_call[i]); }
+    for (int i = 0; i < ZE_STREAMS; i++) { ws_free(e->ws[i]); hipStreamDestroy(e->st[i]); hipEventDestroy(e->ev_scan[i]); }
+    for (int i = 0; i < 2; i++) hipEventDestroy(e->ev_call[i]);
+    hipEventDestroy(e->ev_init);
     for (int i = 0; i < e->cap_tm; i++) { hipEventDestroy(e->tm[i].a); hipEventDestroy(e->tm[i].b); }
     free(e->tm);
     hipFree(e->d_total); hipFree(e->d_err); hipFree(e->d_off_own); hipFree(e->d_ck_a); hipFree(e->d_ck_c);
@@ -1017,14 +1024,15 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
     /* batch size from the workspace budget, two batches in flight */
     uint64_t per = ws_bytes_per_chunk(chunk_size, P.max_blocks);
-    uint64_t bc = e->ws_budget / 2 / per;
+    const int NS = getenv("ZAMD_SERIAL") ? 1 : e->nstreams;
+    uint64_t bc = e->ws_budget / (uint64_t)NS / per;
     if (bc < 1) bc = 1;
     if (bc > total_chunks) bc = total_chunks;
-    if (total_chunks > bc && total_chunks < 2 * bc) bc = (total_chunks + 1) / 2;
+    if (total_chunks > bc && total_chunks < (uint64_t)NS * bc) bc = (total_chunks + NS - 1) / NS;
     if (bc > 0x7fffffu) bc = 0x7fffffu;
     const uint32_t batch = (uint32_t)bc;
     const uint32_t nbatches = (uint32_t)((total_chunks + batch - 1) / batch);
-    for (int i = 0; i < (nbatches > 1 ? 2 : 1); i++) { rc = ws_ensure(e->ws[i], batch, chunk_size, P.max_blocks); if (rc) return rc; }
+    for (int i = 0; i < NS && (uint32_t)i < nbatches; i++) { rc = ws_ensure(e->ws[i], batch, chunk_size, P.max_blocks); if (rc) return rc; }
     uint64_t *d_off = d_chunk_off;
     if (!d_off) {
         if (e->d_off_cap < total_chunks + 1) { hipFree(e->d_off_own); e->d_off_own = nullptr; e->d_off_cap = 0;
@@ -1037,10 +1045,11 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     HIPCHK(hipMemsetAsync(e->d_total, 0, 8, s0));
     HIPCHK(hipMemsetAsync(e->d_err, 0, 4, s0));
     HIPCHK(hipMemsetAsync(d_out, 0, out_cap, s0));
-    HIPCHK(hipEventRecord(e->ev_scan[1], s0));          /* batch 0's predecessor "scan" */
+    HIPCHK(hipEventRecord(e->ev_init, s0));
+    HIPCHK(hipEventRecord(e->ev_scan[NS - 1], s0));     /* batch 0's predecessor "scan" */
     const uint32_t tiles = (chunk_size + ZK_TILE - 1) / ZK_TILE;
     for (uint32_t bi = 0; bi < nbatches; bi++) {
-        const int si = getenv("ZAMD_SERIAL") ? 0 : (int)(bi & 1u);
+        const int si = (int)(bi % (uint32_t)NS);
         hipStream_t s = e->st[si];
         ZeWorkspace &w = e->ws[si];
         ZkJob J; memset(&J, 0, sizeof J);
@@ -1055,7 +1064,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         J.chunk_off = d_off; J.running_total = e->d_total;
         J.out32 = (uint32_t *)d_out; J.out_cap = out_cap; J.err = e->d_err;
         int slot;
-        if (bi == 1) HIPCHK(hipStreamWaitEvent(s, e->ev_scan[1], 0));   /* memsets on stream 0 */
+        if (bi >= 1 && bi < (uint32_t)NS) HIPCHK(hipStreamWaitEvent(s, e->ev_init, 0));   /* memsets on stream 0 */
         if (P.parser == ZC_PARSE_SLOW) {
             tm_begin(e, s, 0, &slot);
             hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(ZK_CHAIN_THREADS), 0, s, J);
@@ -1090,7 +1099,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         tm_begin(e, s, 4, &slot);
         hipLaunchKernelGGL(k_layout, dim3((J.nchunks + 255) / 256), dim3(256), 0, s, J);
         /* output offsets chain from batch to batch through d_total */
-        HIPCHK(hipStreamWaitEvent(s, e->ev_scan[si ^ 1], 0));
+        HIPCHK(hipStreamWaitEvent(s, e->ev_scan[(si + NS - 1) % NS], 0));
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, J);
         HIPCHK(hipEventRecord(e->ev_scan[si], s));
         tm_end(e, s, slot);
@@ -1100,7 +1109,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (bi == 0) { e->last_job = J; e->have_last = true; }
     }
     HIPCHK(hipGetLastError());
-    if (nbatches > 1) { HIPCHK(hipStreamSynchronize(e->st[1])); }
+    for (int i = 1; i < NS && (uint32_t)i < nbatches; i++) HIPCHK(hipStreamSynchronize(e->st[i]));
     HIPCHK(hipEventRecord(e->ev_call[1], s0));
     HIPCHK(hipStreamSynchronize(s0));
     uint64_t total = 0; uint32_t err = 0;
