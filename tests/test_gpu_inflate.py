@@ -148,3 +148,21 @@ def test_shard_with_head_window(engine):
     head = data[k * chunk - 32768:k * chunk]
     out = engine.inflate_chunks(sub, sub_offs, len(data) - k * chunk, chunk_size=chunk, head_window=head)
     assert out == data[k * chunk:]
+
+
+def test_results_do_not_depend_on_stale_device_memory(engine):
+    # workspace buffers are reused between calls: poison freed memory, then run small and ragged cases
+    for fill in (0x55, 0xff):
+        junk = [engine.alloc(96 << 20) for _ in range(4)]
+        for jbuf in junk:
+            engine.lib.zamd_dev_memset(engine.handle, jbuf.ptr, fill, jbuf.nbytes)
+        for jbuf in junk:
+            jbuf.free()
+        for n, chunk in ((1, 32768), (40000, 32768), (100001, 65536), (3 * 65536 + 7, 65536)):
+            data = O.corpus(n, 0, 77)
+            stream, offs = engine.deflate_chunks(data, level=6, chunk_size=chunk)
+            assert engine.inflate_chunks(stream, offs, n, chunk_size=chunk) == data
+            comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+            blob = comp.compress(data) + comp.flush()
+            res, out = engine.inflate_segments(blob, [_one_segment(engine, blob, out_cap=n, mode=zlib_amd.INF_EXACT)], out_bytes=max(n, 16))
+            assert res[0]["status"] == 1 and out[:n] == data

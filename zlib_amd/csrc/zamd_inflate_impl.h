@@ -647,7 +647,7 @@ __global__ __launch_bounds__(1024) void k_inf_ref_init(const ZiSeg *segs, const 
     const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
     const ZiSeg S = segs[si];
     const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
-    if (e >= tl) return;
+    if (e >= tl) { ref[(uint64_t)si * 32768u + e] = 0x80000000u; return; }   /* every slot is read by the jump rounds */
     const uint32_t v = out16[S.out_off + S.out_len - tl + e];
     uint32_t r;
     if (v < ZI_MARK) r = 0x80000000u | v;
@@ -857,7 +857,7 @@ extern "C" int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uin
     HIPCHK(hipMemcpy(e->inf->d_segs, segs, nseg * sizeof(ZiSeg), hipMemcpyHostToDevice));
     /* every segment is reported, so a failing one is not an error of the call */
     int64_t bad = -1;
-    bool regular = true;            /* every segment but the last at least 32 KiB long and back to back */
+    bool regular = segs[0].out_off == 0;   /* and every segment but the last at least 32 KiB long and back to back */
     for (uint64_t i = 0; i + 1 < nseg && regular; i++)
         regular = segs[i].out_cap >= 32768 && segs[i].out_off + segs[i].out_cap == segs[i + 1].out_off && (segs[i].mode & ZAMD_INF_EXACT);
     rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad, regular);
