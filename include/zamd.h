@@ -66,10 +66,11 @@ int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chun
 
 /*
  * The same for one shard of a larger input (multi-GPU sharding by chunk range):
- * the head_dict_len (0 or 32768) bytes in front of d_in are device-resident too
- * and are the dictionary of the shard's first chunk, exactly as the previous
- * 32 KiB are for every later chunk.  Pass finish = 1 only on the shard that
- * holds the end of the input.
+ * the head_dict_len bytes (a multiple of 16, at most 32768) in front of d_in are
+ * device-resident too and are the dictionary of the shard's first chunk, exactly
+ * as the previous 32 KiB are for every later chunk — the tail of the previous
+ * shard, or a preset dictionary (deflateSetDictionary, deflate.c:323).  Pass
+ * finish = 1 only on the shard that holds the end of the input.
  */
 int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t head_dict_len, uint32_t chunk_size,
                            int level, int strategy, int mem_level, int finish,

@@ -109,8 +109,11 @@ int deflateParams(z_streamp strm, int level, int strategy);                     
 int deflatePending(z_streamp strm, unsigned *pending, int *bits);                                   /* :450 */
 int deflateSetHeader(z_streamp strm, gz_headerp head);                                              /* :439 */
 int deflateCopy(z_streamp dest, z_streamp source);                                                  /* :1014 */
-/* accepted by the reference, not supported by the chunked engine: return Z_STREAM_ERROR */
+/* The dictionary primes the first chunk.  The engine takes it in multiples of 16
+ * bytes: for other lengths the oldest dictLength % 16 bytes are not matched against
+ * (the stream stays valid for the full dictionary, dictid covers all of it). */
 int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength);                 /* :323 */
+/* accepted by the reference, not supported by the chunked engine: return Z_STREAM_ERROR */
 int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain);     /* :531 */
 int deflatePrime(z_streamp strm, int bits, int value);                                              /* :464 */
 

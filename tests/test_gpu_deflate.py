@@ -155,3 +155,24 @@ def test_errors_are_loud(engine):
     assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 6, 7, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
     d.upload(bytes(os.urandom(1 << 16)))
     assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 6, 0, 8, 1, o.ptr, 1024, None, C.byref(tot)) == zlib_amd.Z_BUF_ERROR
+
+
+@pytest.mark.parametrize("head", [16, 4096, 32752])
+def test_shard_entry_point_with_a_short_head_dictionary(engine, head):
+    data = O.corpus(head + 200000, 0, 44)
+    chunk = 65536
+    n = len(data) - head
+    nch = (n + chunk - 1) // chunk
+    cap = engine.lib.zamd_deflate_bound(n, chunk, 8)
+    d_in, d_out, d_off = engine.alloc(32768 + n), engine.alloc(cap), engine.alloc(8 * (nch + 1))
+    d_in.upload(data, offset=32768 - head)
+    total = engine.deflate_shard_dev(d_in.ptr + 32768, n, head, d_out.ptr, cap, level=6, chunk_size=chunk, d_chunk_off=d_off.ptr)
+    out = bytes(d_out.download(total))
+    offs = list(memoryview(d_off.download(8 * (nch + 1))).cast("Q"))
+    want = b""
+    for c in range(nch):
+        start = head + c * chunk
+        dl = min(start, 32768)
+        ln = min(chunk, len(data) - start)
+        want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, 6, 0, 8, c == nch - 1)
+    assert out == want and offs[-1] == len(want)

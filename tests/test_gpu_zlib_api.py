@@ -197,3 +197,41 @@ def test_params_change_mid_stream():
     assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
     assert zlib.decompress(obuf.raw[:s.total_out]) == data
     assert l.deflateEnd(C.byref(s)) == Z.Z_OK
+
+
+def _deflate_with_dict(data, d, level=6, wbits=15):
+    l = Z.lib()
+    s = Z.ZStream()
+    assert l.deflateInit2_(C.byref(s), level, 8, wbits, 8, 0, Z.VERSION, Z.SZ) == 0
+    assert l.deflateSetDictionary(C.byref(s), d, len(d)) == Z.Z_OK
+    src = C.create_string_buffer(data, max(len(data), 1))
+    cap = len(data) + len(data) // 8 + 4096
+    obuf = C.create_string_buffer(cap)
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(data), C.addressof(obuf), cap
+    assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+    out = obuf.raw[:s.total_out]
+    adler = s.adler
+    assert l.deflateEnd(C.byref(s)) == Z.Z_OK
+    return out, adler
+
+
+def test_preset_dictionary_on_deflate():
+    data = O.corpus(200000, 0, 31)
+    # a dictionary the engine can take whole (multiple of 16 bytes): the reference's bytes exactly
+    d = O.corpus(16000, 0, 31)
+    out, adler = _deflate_with_dict(data, d)
+    want = bytes([0x78, 0xbb]) + zlib.adler32(d).to_bytes(4, "big") + O.deflate_chunk(d + data, len(d), len(data), 6, 0, 8, True) \
+        + zlib.adler32(data).to_bytes(4, "big")
+    assert out == want
+    assert adler == zlib.adler32(data)
+    assert zlib.decompressobj(15, d).decompress(out) == data
+    # any other length, and more than a window: valid streams for the same dictionary
+    for dl in (1, 15, 1001, 32768, 50000):
+        d = O.corpus(dl, 0, 32)
+        out, _ = _deflate_with_dict(data, d)
+        assert zlib.decompressobj(15, d).decompress(out) == data
+        raw, _ = _deflate_with_dict(data, d, wbits=-15)
+        assert zlib.decompressobj(-15, d).decompress(raw) == data
+    # our own inflate takes it back through Z_NEED_DICT
+    rc, back, msg, unused, _ = Z.inflate_stream(out, 15, dictionary=d)
+    assert rc == Z.Z_STREAM_END and back == data

@@ -1010,7 +1010,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                                       void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out)
 {
     if (!e || !d_out || (!d_in && n)) return ZAMD_STREAM_ERROR;
-    if (head_dict_len != 0 && head_dict_len != ZC_WSIZE) return ZAMD_STREAM_ERROR;
+    if (head_dict_len > ZC_WSIZE || (head_dict_len & 15u)) return ZAMD_STREAM_ERROR;
     if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
     ZcParams P;
     int rc = fill_params(P, level, strategy, mem_level, chunk_size);

@@ -95,7 +95,8 @@ struct DState {
     uint32_t chunk_size;
     uint64_t batch_bytes;
     gz_headerp gzhead;
-    bool trailer_done;
+    bool trailer_done, have_dict;
+    uint32_t dictid;
     uint32_t hist_len;                 // bytes of history kept in `hist` (== HIST once warm)
     uint64_t since_reset;              // input bytes compressed since the last history reset
     std::vector<uint8_t> hist;         // last 32 KiB of compressed input
@@ -166,8 +167,10 @@ void write_header(z_streamp strm, DState *s) {     // deflate.c:690-867
         else if (s->level == 6) level_flags = 2;
         else level_flags = 3;
         header |= level_flags << 6;
+        if (s->have_dict) header |= 0x20;                 // PRESET_DICT, deflate.c:750
         header += 31 - (header % 31);
         o.push_back(header >> 8); o.push_back(header & 0xff);
+        if (s->have_dict) put_be32(o, s->dictid);         // deflate.c:757-760
         strm->adler = 1;                                  // adler32(0, NULL, 0)
     }
     s->status = ST_BUSY;
@@ -179,12 +182,12 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     std::lock_guard<std::mutex> lk(g_gpu.mu);
     zamd_engine *e = engine_locked();
     if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
-    uint32_t head = s->hist_len == HIST ? HIST : 0;
+    uint32_t head = s->hist_len & ~15u;            // the engine takes its dictionary in multiples of 16 bytes: drop the oldest few
     uint64_t bound = zamd_deflate_bound(n, s->chunk_size, s->mem_level);
     if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, HIST + n + 64) != Z_OK) return Z_MEM_ERROR;
     if (grow(e, &g_gpu.d_out, &g_gpu.out_cap, bound + 64) != Z_OK) return Z_MEM_ERROR;
     int rc = 0;
-    if (head) rc = zamd_dev_upload(e, g_gpu.d_in, s->hist.data(), HIST);
+    if (head) rc = zamd_dev_upload(e, g_gpu.d_in + (HIST - head), s->hist.data() + (s->hist_len - head), head);
     if (rc == 0 && n) rc = zamd_dev_upload(e, g_gpu.d_in + HIST, src, n);
     uint64_t total = 0;
     if (rc == 0)
@@ -297,6 +300,7 @@ int deflateResetKeep(z_streamp strm) {
     strm->adler = s->wrap == 2 ? 0 : 1;
     s->last_flush = Z_NO_FLUSH;
     s->trailer_done = false;
+    s->have_dict = false; s->dictid = 0;
     return Z_OK;
 }
 
@@ -325,9 +329,19 @@ int deflatePending(z_streamp strm, unsigned *pending, int *bits) {
     return Z_OK;
 }
 
-int deflateSetDictionary(z_streamp strm, const Bytef *, uInt) {
-    if (strm) strm->msg = "preset dictionaries are not supported by the GPU engine";
-    return Z_STREAM_ERROR;
+int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength) {    // deflate.c:323-389
+    DState *s = dstate(strm);
+    if (!s || dictionary == Z_NULL) return Z_STREAM_ERROR;
+    if (s->wrap == 2 || (s->wrap == 1 && s->status != ST_INIT) || !s->in.empty() || s->since_reset != 0) return Z_STREAM_ERROR;
+    if (s->wrap == 1) {
+        uLong id = adler32(strm->adler, dictionary, dictLength);
+        strm->adler = id; s->dictid = (uint32_t)id; s->have_dict = true;
+    }
+    // the window keeps the last 32 KiB (deflate.c:347-356); it primes the first chunk
+    uInt keep = dictLength > HIST ? HIST : dictLength;
+    s->hist.assign(dictionary + (dictLength - keep), dictionary + dictLength);
+    s->hist_len = keep;
+    return Z_OK;
 }
 int deflateTune(z_streamp strm, int, int, int, int) {
     if (strm) strm->msg = "deflateTune is not supported by the GPU engine";
