@@ -49,6 +49,7 @@ struct ZkJob {
     uint64_t *running_total;      /* bytes written by earlier batches */
     uint32_t *out32; uint64_t out_cap;
     uint32_t *err;
+    uint16_t *fhead;              /* levels 1-3: head table of every chunk of the batch, 65536 entries each */
 };
 
 /* ------------------------------------------------------------------ k_chain
@@ -851,6 +852,7 @@ struct ZeWorkspace {
     ZcBlock *blk = nullptr; ZcBlockTab *tab = nullptr;
     uint32_t *nblk = nullptr, *nsym = nullptr; uint64_t *chunk_bytes = nullptr, *sync_bit = nullptr;
     uint64_t pdist_len = 0;
+    uint16_t *fhead = nullptr; uint32_t fhead_chunks = 0;
 };
 
 #define ZE_STREAMS 8            /* batches in flight at most */
@@ -878,7 +880,7 @@ struct zamd_engine {
 static void ws_free(ZeWorkspace &w)
 {
     hipFree(w.pdist); hipFree(w.rec); hipFree(w.sym); hipFree(w.hop); hipFree(w.nhop); hipFree(w.blk); hipFree(w.tab);
-    hipFree(w.nblk); hipFree(w.nsym); hipFree(w.chunk_bytes); hipFree(w.sync_bit);
+    hipFree(w.nblk); hipFree(w.nsym); hipFree(w.chunk_bytes); hipFree(w.sync_bit); hipFree(w.fhead);
     w = ZeWorkspace();
 }
 
@@ -1015,10 +1017,6 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     ZcParams P;
     int rc = fill_params(P, level, strategy, mem_level, chunk_size);
     if (rc) return rc;
-    if (P.parser == ZC_PARSE_FAST && P.hash_bits > 15) {
-        fprintf(stderr, "zamd: levels 1-3 with memLevel 9 are not supported (the head table does not fit the LDS)\n");
-        return ZAMD_STREAM_ERROR;
-    }
     out_cap &= ~15ull;
     HIPCHK(hipSetDevice(e->device));
     const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
@@ -1085,7 +1083,15 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             tm_end(e, s, slot);
         }
         tm_begin(e, s, 2, &slot);
-        if (P.parser == ZC_PARSE_FAST) hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
+        if (P.parser == ZC_PARSE_FAST) {
+            if (w.fhead_chunks < batch) {
+                hipFree(w.fhead); w.fhead = nullptr; w.fhead_chunks = 0;
+                HIPCHK(hipMalloc((void **)&w.fhead, (uint64_t)batch * 65536u * 2u)); w.fhead_chunks = batch;
+            }
+            J.fhead = w.fhead;
+            HIPCHK(hipMemsetAsync(w.fhead, 0, (uint64_t)J.nchunks * 65536u * 2u, s));
+            hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
+        }
         else if (P.parser == ZC_PARSE_SLOW && !getenv("ZAMD_SERIAL_PARSE")) {
             const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
             hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
