@@ -997,6 +997,7 @@ static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint
 }
 
 __global__ void k_fast(ZkJob J);
+#define ZF_ROW (65536u + 32768u)
 static void tm_begin(zamd_engine *e, hipStream_t s, int which, int *slot)
 {
     *slot = -1;
@@ -1086,10 +1087,10 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (P.parser == ZC_PARSE_FAST) {
             if (w.fhead_chunks < batch) {
                 hipFree(w.fhead); w.fhead = nullptr; w.fhead_chunks = 0;
-                HIPCHK(hipMalloc((void **)&w.fhead, (uint64_t)batch * 65536u * 2u)); w.fhead_chunks = batch;
+                HIPCHK(hipMalloc((void **)&w.fhead, (uint64_t)batch * ZF_ROW * 2u)); w.fhead_chunks = batch;
             }
             J.fhead = w.fhead;
-            HIPCHK(hipMemsetAsync(w.fhead, 0, (uint64_t)J.nchunks * 65536u * 2u, s));
+            HIPCHK(hipMemsetAsync(w.fhead, 0, (uint64_t)J.nchunks * ZF_ROW * 2u, s));
             hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
         else if (P.parser == ZC_PARSE_SLOW && !getenv("ZAMD_SERIAL_PARSE")) {

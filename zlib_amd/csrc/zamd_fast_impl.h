@@ -7,68 +7,51 @@
  * by ONE wavefront that owns the chunk's head[] and prev[] as 16-bit window
  * indices, exactly as the reference lays them out.  The state machine
  * (zc_parse_fast) is wave-uniform; what keeps it off the memory latency:
- *   - the last 64 KiB of input live in an LDS ring (filled 1 KiB at a time, well
- *     ahead of the parse), prev[] lives in LDS too;
- *   - head[] lives in global memory, but never on the critical path: the hashes
+ *   - a lone wavefront issues at most one instruction every four cycles, so what
+ *     counts is how many chunks a CU parses at once: the LDS holds only prev[] of
+ *     the newest 8 Ki positions (16 KiB: ten wavefronts per CU);
+ *     older links, head[] and the input bytes are read from global memory;
+ *   - head[] is never on the critical path: the hashes
  *     of the next 128 positions are computed by the lanes and their head entries
  *     gathered one batch ahead; an insertion patches the gathered values of later
  *     positions with the same hash in registers, so a position's head entry is a
  *     v_readlane away when the parse gets there;
  *   - the candidates of a chain walk are compared with the current string all at
- *     once, one per lane, out of the ring.
+ *     once, one per lane.
  */
 
-#define ZF_RING      65536u
-#define ZF_RING_PAD  288u       /* the first bytes are mirrored behind the end: reads of <= 272 bytes never wrap */
+#define ZF_NEAR 8192u       /* links of the newest ZF_NEAR positions are kept in LDS (16 KiB: ten wavefronts per CU) */
 
 struct ZkFastCtx {
     const uint8_t *b;             /* a-coordinate 0 */
     uint64_t readable;            /* bytes of b that may be read */
     uint32_t E;                   /* end of the chunk's data (a-coordinate) */
-    uint8_t *ring; uint16_t *prev; uint16_t *fhead;
+    uint16_t *prev_l;             /* LDS: prev[] of the newest ZF_NEAR window indices */
+    uint16_t *prev_g, *fhead;     /* global: all of prev[] (32768 entries), head[] */
     uint32_t hshift, hmask, hsize, nice, chain, lane;
-    uint32_t ring_hi;             /* ring holds a-coordinates [ring_hi - ZF_RING, ring_hi) */
     uint32_t q0;                  /* first position of the current batch */
     uint32_t h_cur, hv_cur, h_nxt, hv_nxt;   /* per lane: hash and head entry of q0 + lane, q0 + 64 + lane */
-    uint32_t curB;                /* window base the gathered entries are relative to */
 
-    __device__ __forceinline__ void fill_ring(uint32_t upto)
+    __device__ __forceinline__ uint32_t bytes4(uint32_t a) const
     {
-        while (ring_hi < upto) {
-            const uint32_t a = ring_hi + lane * 16u;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if ((uint64_t)a + 16u <= readable) v = *(const uint4 *)(b + a);
-            else if (a < readable) {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (uint32_t i = 0; i < 16 && (uint64_t)a + i < readable; i++) t[i >> 2] |= (uint32_t)b[a + i] << (8u * (i & 3u));
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            }
-            const uint32_t r = a & (ZF_RING - 1u);
-            *(uint4 *)(ring + r) = v;
-            if (r < ZF_RING_PAD) *(uint4 *)(ring + ZF_RING + r) = v;
-            ring_hi += 1024u;
-        }
-    }
-    __device__ __forceinline__ uint32_t load4(uint32_t a) const
-    {
-        const uint32_t r = a & (ZF_RING - 1u), i = r >> 2;
-        const uint32_t *w = (const uint32_t *)ring;
-        return __builtin_amdgcn_alignbyte(w[i + 1], w[i], r & 3u);
+        uint32_t w = 0;
+        if ((uint64_t)a + 4u <= readable) __builtin_memcpy(&w, b + a, 4);
+        else for (uint32_t i = 0; i < 4 && (uint64_t)a + i < readable; i++) w |= (uint32_t)b[a + i] << (8u * i);
+        return w;
     }
     /* hashes and head entries of the 64 positions from qb on */
     __device__ __forceinline__ void load_batch(uint32_t qb, uint32_t &h, uint32_t &hv)
     {
         const uint32_t a = qb + lane;
         const bool ok = a + ZC_MIN_MATCH <= E;
-        const uint32_t w = load4(a);
+        const uint32_t w = ok ? bytes4(a) : 0u;
         h = ok ? zc_hash3(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, hshift, hmask) : 0xffffffffu;
         hv = ok ? (uint32_t)fhead[h] : 0u;
     }
-    __device__ __forceinline__ void start_batches(uint32_t q, uint32_t B)
+    __device__ __forceinline__ void start_batches(uint32_t q)
     {
-        fill_ring(q + 2048u);
         __threadfence_block();                 /* earlier head stores have landed */
-        q0 = q; curB = B;
+        q0 = q;
         load_batch(q0, h_cur, hv_cur);
         load_batch(q0 + 64u, h_nxt, hv_nxt);
     }
@@ -76,37 +59,40 @@ struct ZkFastCtx {
     {
         if (p - q0 >= 64u) {
             if (p - q0 < 128u) {
-                if (ring_hi < p + 1024u) fill_ring(p + 8192u);
                 h_cur = h_nxt; hv_cur = hv_nxt; q0 += 64u;
                 __threadfence_block();
                 load_batch(q0 + 64u, h_nxt, hv_nxt);
-            } else start_batches(p, B);
+            } else start_batches(p);
         }
         const uint32_t k = p - q0, wi = p - B;
         const uint32_t hq = __builtin_amdgcn_readlane(h_cur, k);
         const uint32_t e = __builtin_amdgcn_readlane(hv_cur, k);
         hv_cur = (lane > k && h_cur == hq) ? wi : hv_cur;
         hv_nxt = h_nxt == hq ? wi : hv_nxt;
-        if (lane == 0) { prev[wi & 32767u] = (uint16_t)e; fhead[hq] = (uint16_t)wi; }
+        if (lane == 0) { prev_l[wi & (ZF_NEAR - 1u)] = (uint16_t)e; prev_g[wi & 32767u] = (uint16_t)e; fhead[hq] = (uint16_t)wi; }
         return e;
+    }
+    __device__ __forceinline__ void rebase(uint16_t *t, uint32_t n)
+    {
+        for (uint32_t i = lane * 8u; i < n; i += 512u) {
+            uint4 q = *(uint4 *)(t + i);
+            uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t lo = v[j] & 0xffffu, hi = v[j] >> 16;
+                v[j] = (lo >= 32768u ? lo - 32768u : 0u) | ((hi >= 32768u ? hi - 32768u : 0u) << 16);
+            }
+            *(uint4 *)(t + i) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
     }
     __device__ __forceinline__ void slide()
     {
         __threadfence_block();
-        for (uint32_t i = lane * 8u; i < hsize; i += 512u) {
-            uint4 q = *(uint4 *)(fhead + i);
-            uint32_t t[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t lo = t[j] & 0xffffu, hi = t[j] >> 16;
-                t[j] = (lo >= 32768u ? lo - 32768u : 0u) | ((hi >= 32768u ? hi - 32768u : 0u) << 16);
-            }
-            *(uint4 *)(fhead + i) = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-        for (uint32_t i = lane; i < 32768u; i += 64) { const uint32_t m = prev[i]; prev[i] = (uint16_t)(m >= 32768u ? m - 32768u : 0u); }
+        rebase(fhead, hsize);
+        rebase(prev_g, 32768u);
+        for (uint32_t i = lane; i < ZF_NEAR; i += 64) { const uint32_t m = prev_l[i]; prev_l[i] = (uint16_t)(m >= 32768u ? m - 32768u : 0u); }
         hv_cur = hv_cur >= 32768u ? hv_cur - 32768u : 0u;
         hv_nxt = hv_nxt >= 32768u ? hv_nxt - 32768u : 0u;
-        curB += 32768u;
         __threadfence_block();
     }
     /* longest_match (deflate.c:1148-1289) with prev_length 2: the chain is walked
@@ -117,22 +103,29 @@ struct ZkFastCtx {
     {
         const uint32_t sw = p - B, limit = sw > ZC_MAX_DIST ? sw - ZC_MAX_DIST : 0u;
         const uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH, nice_eff = nice < look ? nice : look;
-        if (ring_hi < p + 512u) fill_ring(p + 8192u);
         uint32_t candv = 0, n = 0;
         do {
             candv = lane == n ? cur : candv;
             n++;
-            cur = zi_uni(prev[cur & 32767u]);
+            cur = sw - cur < ZF_NEAR ? zi_uni(prev_l[cur & (ZF_NEAR - 1u)]) : zi_uni(prev_g[cur & 32767u]);
         } while (cur > limit && n < chain);
         uint32_t len = 0;
         if (lane < n) {
-            const uint32_t m = B + candv;
+            const uint8_t *m = b + B + candv, *s = b + p;
+            const bool wide = (uint64_t)p + cap + 16u <= readable;      /* candidates lie below p */
             while (len < cap) {
-                const uint32_t x0 = load4(m + len) ^ load4(p + len);
-                if (x0) { len += zc_ctz32(x0) >> 3; break; }
-                const uint32_t x1 = load4(m + len + 4u) ^ load4(p + len + 4u);
-                if (x1) { len += 4u + (zc_ctz32(x1) >> 3); break; }
-                len += 8;
+                if (wide) {
+                    uint64_t a0, a1, c0, c1;
+                    __builtin_memcpy(&a0, m + len, 8); __builtin_memcpy(&a1, m + len + 8, 8);
+                    __builtin_memcpy(&c0, s + len, 8); __builtin_memcpy(&c1, s + len + 8, 8);
+                    const uint64_t x0 = a0 ^ c0, x1 = a1 ^ c1;
+                    if (x0) { len += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
+                    if (x1) { len += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
+                    len += 16;
+                } else {
+                    if (m[len] != s[len]) break;
+                    len++;
+                }
             }
             if (len > cap) len = cap;
         }
@@ -145,21 +138,24 @@ struct ZkFastCtx {
     }
 };
 
+/* global tables of one chunk: head[65536] then prev[32768], 16-bit window indices */
+#ifndef ZF_ROW
+#define ZF_ROW (65536u + 32768u)
+#endif
+
 __global__ __launch_bounds__(64) void k_fast(ZkJob J)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[ZF_RING + ZF_RING_PAD];
-    __shared__ uint16_t s_prev[32768];
+    __shared__ __attribute__((aligned(16))) uint16_t s_prev[ZF_NEAR];
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     ZkFastCtx cx;
     cx.b = J.in + g.dstart; cx.readable = J.n - g.dstart; cx.E = g.dict_len + g.len;
-    cx.ring = s_ring; cx.prev = s_prev; cx.fhead = J.fhead + (uint64_t)lc * 65536u;
+    cx.prev_l = s_prev; cx.fhead = J.fhead + (uint64_t)lc * ZF_ROW; cx.prev_g = cx.fhead + 65536u;
     cx.hshift = J.P.hash_shift; cx.hmask = J.P.hash_mask; cx.hsize = J.P.hash_mask + 1u;
     cx.nice = J.P.nice; cx.chain = J.P.chain; cx.lane = lane;
-    cx.ring_hi = 0;
-    for (uint32_t i = lane; i < 32768u; i += 64) s_prev[i] = 0;
+    for (uint32_t i = lane; i < ZF_NEAR; i += 64) s_prev[i] = 0;
     __syncthreads();
-    cx.start_batches(0, 0);
+    cx.start_batches(0);
     GSym sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size; sym.lane = lane;
     GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
     uint32_t nsym = 0;
