@@ -235,3 +235,22 @@ def test_preset_dictionary_on_deflate():
     # our own inflate takes it back through Z_NEED_DICT
     rc, back, msg, unused, _ = Z.inflate_stream(out, 15, dictionary=d)
     assert rc == Z.Z_STREAM_END and back == data
+
+
+def test_preloaded_under_a_program_linked_against_libz():
+    """Python's own zlib module is linked against the system libz; with libzamd_z.so preloaded the same
+    module runs on the GPU library (tests/gpu_preload_check.py prints one line per check)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    ours = os.path.join(Z.ROOT, "zlib_amd", "libzamd_z.so")
+    env["LD_PRELOAD"] = (env.get("LD_PRELOAD", "") + " " + ours).strip()
+    r = subprocess.run([sys.executable, os.path.join(Z.ROOT, "tests", "gpu_preload_check.py")], cwd=Z.ROOT, env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if ":" in l]
+    assert "runtime version: 1.2.8" in r.stdout
+    assert "error text: Error -3 while decompressing data: invalid block type" in r.stdout
+    checks = [l for l in lines if l.split(":")[0] not in ("runtime version", "error text")]
+    assert len(checks) == 5 and all("False" not in l for l in checks), r.stdout
