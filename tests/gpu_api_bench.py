@@ -1,0 +1,40 @@
+"""Manual tool: host-buffer (PCIe-inclusive) rate of the stream API.  usage: gpu_api_bench.py [MiB] [level]"""
+import ctypes as C
+import sys
+import time
+
+sys.path.insert(0, "tests")
+import _zapi as Z
+import zlib_amd
+
+mib = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+level = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+n = mib << 20
+data = zlib_amd.corpus(n, 4, 5, piece_bytes=16 << 20, threads=16)
+src = (C.c_char * n).from_buffer(data)
+l = Z.lib()
+cap = l.compressBound(n)
+out = C.create_string_buffer(cap)
+back = C.create_string_buffer(n)
+for it in range(2):
+    s = Z.ZStream()
+    assert l.deflateInit2_(C.byref(s), level, 8, 31, 8, 0, Z.VERSION, Z.SZ) == 0
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), n, C.addressof(out), cap
+    t0 = time.time()
+    rc = l.deflate(C.byref(s), Z.Z_FINISH)
+    dt = time.time() - t0
+    assert rc == Z.Z_STREAM_END, rc
+    total = s.total_out
+    l.deflateEnd(C.byref(s))
+    print("deflate(): %d -> %d in %.1f ms = %.2f GB/s (host buffers, gzip wrapper)" % (n, total, dt * 1e3, n / dt / 1e9), flush=True)
+for it in range(2):
+    s = Z.ZStream()
+    assert l.inflateInit2_(C.byref(s), 47, Z.VERSION, Z.SZ) == 0
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(out), total, C.addressof(back), n
+    t0 = time.time()
+    rc = l.inflate(C.byref(s), Z.Z_FINISH)
+    dt = time.time() - t0
+    assert rc == Z.Z_STREAM_END, (rc, s.msg)
+    l.inflateEnd(C.byref(s))
+    print("inflate(): %.1f ms = %.2f GB/s of output (host buffers)" % (dt * 1e3, n / dt / 1e9), flush=True)
+print("round trip", "OK" if back.raw == bytes(data) else "MISMATCH")

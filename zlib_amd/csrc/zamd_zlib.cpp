@@ -9,6 +9,9 @@
 // Reference behaviour mirrored here: deflate.c:201-320 (init), :392-436 (reset),
 // :665-976 (deflate), :979-1007 (end), compress.c, uncompr.c, inflate.c:104-249,
 // :605-1252 (wrapper handling of inflate), zutil.c:17-40, 136.
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
 #include "../../include/zamd.h"
 #include "../../include/zamd_zlib.h"
 
@@ -200,9 +203,15 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
         strm->adler = v;
     }
     if (rc == 0 && total) {
-        size_t at = s->out.size();
-        s->out.resize(at + total);
-        rc = zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, total);
+        if (s->out.size() == s->out_pos && strm->avail_out >= total) {
+            // nothing pending and room enough: straight into the caller's buffer
+            rc = zamd_dev_download(e, strm->next_out, g_gpu.d_out, total);
+            if (rc == 0) { strm->next_out += total; strm->avail_out -= (uInt)total; strm->total_out += total; }
+        } else {
+            size_t at = s->out.size();
+            s->out.resize(at + total);
+            rc = zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, total);
+        }
     }
     if (rc != 0) return rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : (rc == ZAMD_BUF_ERROR ? Z_BUF_ERROR : Z_STREAM_ERROR);
     // history for the next batch = last 32 KiB of everything compressed since the last reset
@@ -282,7 +291,7 @@ int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int mem
     uint64_t chunk = env_u64("ZAMD_Z_CHUNK", 1u << 20);
     if (chunk < 32768 || chunk > (64u << 20) || (chunk & 16383)) chunk = 1u << 20;
     s->chunk_size = (uint32_t)chunk;
-    uint64_t batch = env_u64("ZAMD_Z_BATCH_MIB", 128) << 20;
+    uint64_t batch = env_u64("ZAMD_Z_BATCH_MIB", 512) << 20;
     if (batch < chunk) batch = chunk;
     s->batch_bytes = batch / chunk * chunk;
     strm->state = (struct internal_state *)s;
@@ -606,11 +615,19 @@ void idrain(z_streamp strm, IState *s) {
 int decode_some(z_streamp strm, IState *s) {
     if (s->in.size() * 8ull <= s->bit_off) return Z_OK;
     // sync-marker candidates: independent starting points for parallel wavefronts
-    for (size_t p = s->scanned < 4 ? 4 : s->scanned + 1; p <= s->in.size(); p++) {
-        const uint8_t *q = s->in.data() + p - 4;
-        if (q[0] == 0 && q[1] == 0 && q[2] == 0xff && q[3] == 0xff) s->cands.push_back(p);
+    {
+        static const uint8_t pat[4] = {0, 0, 0xff, 0xff};
+        const uint8_t *base = s->in.data(), *end = base + s->in.size();
+        const uint8_t *q = base + (s->scanned < 3 ? 0 : s->scanned - 3);     // a marker may straddle the old end
+        while (q + 4 <= end) {
+            const uint8_t *hit = (const uint8_t *)memmem(q, (size_t)(end - q), pat, 4);
+            if (!hit) break;
+            const uint64_t c = (uint64_t)(hit - base) + 4;
+            if (s->cands.empty() || s->cands.back() < c) s->cands.push_back(c);
+            q = hit + 1;
+        }
+        s->scanned = s->in.size();
     }
-    s->scanned = s->in.size();
     std::vector<zamd_inflate_seg> segs;
     const uint64_t end_bits = s->in.size() * 8ull;
     auto add = [&](uint64_t bit, uint32_t win) {
@@ -683,13 +700,22 @@ int decode_some(z_streamp strm, IState *s) {
             if (rc != 0) return Z_MEM_ERROR;
             strm->adler = s->check = v;
         }
-        size_t at = s->out.size();
-        s->out.resize(at + produced);
-        if (zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
+        const uint8_t *got;
+        if (s->out.size() == s->out_pos && strm->avail_out >= produced) {
+            // nothing pending and room enough: straight into the caller's buffer
+            if (zamd_dev_download(e, strm->next_out, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
+            got = strm->next_out;
+            strm->next_out += produced; strm->avail_out -= (uInt)produced; strm->total_out += produced;
+        } else {
+            size_t at = s->out.size();
+            s->out.resize(at + produced);
+            if (zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
+            got = s->out.data() + at;
+        }
         s->total += produced;
-        if (produced >= HIST) s->hist.assign(s->out.end() - HIST, s->out.end());
+        if (produced >= HIST) s->hist.assign(got + produced - HIST, got + produced);
         else {
-            s->hist.insert(s->hist.end(), s->out.end() - produced, s->out.end());
+            s->hist.insert(s->hist.end(), got, got + produced);
             if (s->hist.size() > HIST) s->hist.erase(s->hist.begin(), s->hist.end() - HIST);
         }
     }
