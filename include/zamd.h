@@ -57,7 +57,8 @@ uint64_t zamd_deflate_bound(uint64_t n, uint32_t chunk_size, int mem_level);
  * stream.  d_in and d_out must be 16-byte aligned.  d_chunk_off (device,
  * n_chunks + 1 entries, may be NULL) receives each chunk's byte offset in d_out
  * followed by the total; *total_out (host) receives the total.
- * level 1..9, strategy 0..4 (zlib.h:193-197), mem_level 1..9.
+ * level 0..9 (0 = deflate_stored, deflate.c:1564), strategy 0..4 (zlib.h:193-197),
+ * mem_level 1..9.
  * Blocks the calling thread until the result is in d_out.
  */
 int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chunk_size,

@@ -78,6 +78,8 @@ int main(void)
     for (int l = 2; l <= 8; l++) if (l != 6) chunked_row(4, 5, N, C, l, 0, 8);
     chunked_row(4, 5, N, C, 3, 1, 8); chunked_row(4, 5, N, C, 9, 1, 8); chunked_row(4, 5, N, C, 1, 3, 8); chunked_row(4, 5, N, C, 1, 4, 8);
     chunked_row(0, 7, 2u * 1048576u + 65374u, C, 6, 0, 8); chunked_row(0, 7, 2u * 1048576u + 32600u, C, 6, 0, 8);
+    /* level 0 (deflate_stored) */
+    chunked_row(4, 5, N, C, 0, 0, 8); chunked_row(1, 2, 2u * 1048576u + 777u, C, 0, 0, 1); chunked_row(0, 1, 1048576u + 65531u, C, 0, 4, 9);
     chunked_row(4, 9, 3u * 262144u + 777u, 262144u, 6, 0, 8); chunked_row(0, 9, 3u * 65536u + 5u, 65536u, 9, 0, 8);
     printf("\n],\n\"kat\": [\n"); first = 1;
     uint8_t b[20000]; size_t n;

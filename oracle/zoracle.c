@@ -309,17 +309,20 @@ static void flush_block(enc_t *s, uint32_t p, int last)
     int can_store = s->block_start >= s->base;      /* block_start >= 0 in window terms */
     uint64_t bit_start = s->bits_total;
     int type;
-    make_tree(s, &s->lt, &L_DESC);
-    make_tree(s, &s->dt, &D_DESC);
-    /* build_bl_tree(): trees.c:801-829 */
-    walk_lengths(s, &s->lt, s->lt.max_code, 0);
-    walk_lengths(s, &s->dt, s->dt.max_code, 0);
-    make_tree(s, &s->bt, &BL_DESC);
-    int max_bl;
-    for (max_bl = BL_CODES - 1; max_bl >= 3; max_bl--) if (s->bt.len[bl_order[max_bl]]) break;
-    s->opt_len += 3 * ((uint64_t)max_bl + 1) + 5 + 5 + 4;
-    uint64_t opt_lenb = (s->opt_len + 3 + 7) >> 3, static_lenb = (s->static_len + 3 + 7) >> 3;
-    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    int max_bl = 2;
+    uint64_t opt_lenb, static_lenb;
+    if (s->level > 0) {
+        make_tree(s, &s->lt, &L_DESC);
+        make_tree(s, &s->dt, &D_DESC);
+        /* build_bl_tree(): trees.c:801-829 */
+        walk_lengths(s, &s->lt, s->lt.max_code, 0);
+        walk_lengths(s, &s->dt, s->dt.max_code, 0);
+        make_tree(s, &s->bt, &BL_DESC);
+        for (max_bl = BL_CODES - 1; max_bl >= 3; max_bl--) if (s->bt.len[bl_order[max_bl]]) break;
+        s->opt_len += 3 * ((uint64_t)max_bl + 1) + 5 + 5 + 4;
+        opt_lenb = (s->opt_len + 3 + 7) >> 3; static_lenb = (s->static_len + 3 + 7) >> 3;
+        if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    } else opt_lenb = static_lenb = (uint64_t)stored_len + 5;      /* force a stored block, trees.c:945-948 */
 
     if ((uint64_t)stored_len + 4 <= opt_lenb && can_store) {
         type = 0;                                   /* _tr_stored_block, trees.c:865 */
@@ -502,6 +505,27 @@ static uint32_t parse_huff(enc_t *s)
     return p;
 }
 
+/* deflate_stored(): deflate.c:1564-1619 (level 0).  fill_window() tops the
+ * window up to its full 2 * w_size whenever the lookahead is used up; blocks end
+ * at min(0xffff, pending_buf_size - 5) bytes or as soon as they span MAX_DIST. */
+static uint32_t parse_stored(enc_t *s)
+{
+    uint32_t max_block = 0xffff, p = s->dict_len, look = 0;
+    if (max_block > s->lit_bufsize * 4u - 5u) max_block = s->lit_bufsize * 4u - 5u;
+    for (;;) {
+        if (look <= 1) {
+            refill(s, p);
+            look = s->wend - p;
+            if (look == 0) break;
+        }
+        p += look; look = 0;
+        uint32_t max_start = s->block_start + max_block;
+        if (p >= max_start) { look = p - max_start; p = max_start; flush_block(s, p, 0); }
+        if (p - s->block_start >= s->max_dist) flush_block(s, p, 0);
+    }
+    return p;
+}
+
 void zo_trace_free(zo_trace *t)
 {
     if (!t) return;
@@ -513,7 +537,7 @@ size_t zo_deflate_chunk(const uint8_t *buf, size_t dict_len, size_t n,
                         int final, uint8_t *out, size_t out_cap, zo_trace *trace)
 {
     if (level == -1) level = 6;                                    /* deflate.c:258 */
-    if (level < 1 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9 ||
+    if (level < 0 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9 ||
         wbits < 9 || wbits > 15 || dict_len > (1u << wbits) || dict_len + n > 0xfffffff0u)
         return (size_t)-1;
     build_tables();
@@ -545,12 +569,13 @@ size_t zo_deflate_chunk(const uint8_t *buf, size_t dict_len, size_t n,
     uint32_t p;
     if (strategy == ZO_HUFFMAN_ONLY) p = parse_huff(s);                       /* deflate.c:903-905 */
     else if (strategy == ZO_RLE) p = parse_rle(s);
+    else if (cfg[level].parser == P_STORED) p = parse_stored(s);
     else if (cfg[level].parser == P_FAST) p = parse_fast(s);
     else p = parse_slow(s);
 
     if (final) flush_block(s, p, 1);
     else {
-        if (s->last_lit) flush_block(s, p, 0);
+        if (s->last_lit || (s->level == 0 && p > s->block_start)) flush_block(s, p, 0);   /* deflate.c:1616, 1720, 1850 */
         /* Z_SYNC_FLUSH: empty stored block, deflate.c:926-927, trees.c:865-877 */
         put_bits(s, 0, 3); byte_align(s); put_bits(s, 0x0000, 16); put_bits(s, 0xffff, 16);
     }

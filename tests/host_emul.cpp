@@ -64,7 +64,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
     P.good = cfg[level][0]; P.lazy = cfg[level][1]; P.nice = cfg[level][2]; P.chain = cfg[level][3];
     P.hash_bits = mem_level + 7; P.hash_mask = (1u << P.hash_bits) - 1; P.hash_shift = (P.hash_bits + 2) / 3;
     P.lit_bufsize = 1u << (mem_level + 6);
-    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level < 4 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
+    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level == 0 ? ZC_PARSE_STORED : level < 4 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
     P.chunk_size = chunk_size; P.max_blocks = chunk_size / (P.lit_bufsize - 1) + 3;
 
     /* k_chain: global links */
@@ -106,7 +106,8 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
             cx.head.assign((size_t)1 << P.hash_bits, 0); cx.prev.assign(32768, 0);
             nb = zc_parse_fast(g.dict_len, g.len, g.final, P, cx, symst, blkst, &nsym);
         } else
-        if (P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, P, blkst);
+        if (P.parser == ZC_PARSE_STORED) nb = zc_parse_stored(g.dict_len, g.len, g.final, P, blkst);
+        else if (P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, P, blkst);
         else if (P.parser == ZC_PARSE_RLE) nb = zc_parse_rle(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
         else if (!g_hops) nb = zc_parse_slow(g.dict_len, g.len, g.final, P, rec, symst, blkst, &nsym);
         else {
@@ -160,6 +161,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
             static ZcTree<ZC_L_CODES> lt; static ZcTree<ZC_D_CODES> dt; static ZcTree<ZC_BL_CODES> bt;
             uint32_t hist[320] = {0};
             ZcBlock &b = blk[j];
+            if (b.flags & ZC_BF_STORED) continue;
             for (uint32_t i = 0; i < b.sym_count; i++) {
                 if (b.flags & ZC_BF_IMPLICIT) { hist[win.b[b.in_start + i]]++; continue; }
                 uint32_t s = sym[b.sym_start + i];
@@ -234,8 +236,9 @@ int main(int argc, char **argv)
         uint64_t n = (uint64_t)(rnd() % 4) * cs + ((rnd() & 1) ? tails[rnd() % 15] % cs : rnd() % cs);
         if (it == 0) n = 0;
         if (it == 1) { cs = 65536; n = 65374; }      /* tail-mode slide geometry */
-        int level = 1 + rnd() % 9, strategy = rnd() % 5, mem = (rnd() % 3) ? 8 : 1 + rnd() % 9;
+        int level = rnd() % 10, strategy = rnd() % 5, mem = (rnd() % 3) ? 8 : 1 + rnd() % 9;
         if (rnd() & 1) strategy = 0;
+        if (level == 0 && (strategy == 2 || strategy == 3)) strategy = 0;
         if (level == 9 && n > 300000) level = 8;
         std::vector<uint8_t> in(n + 8);
         int kind = rnd() % 7;

@@ -11,7 +11,7 @@ import _oracle as O
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "deflate_golden.json")))
-GPU_LEVELS = range(1, 10)   # deflate_fast (1-3) and deflate_slow (4-9)
+GPU_LEVELS = range(0, 10)   # deflate_stored (0), deflate_fast (1-3) and deflate_slow (4-9)
 
 
 def _gpu(engine, data, **kw):
@@ -54,6 +54,10 @@ for n in (0, 1, 2, 3, 4, 261, 262, 263, 16383, 16384, 32767, 32768, 32769, 65274
     CASES.append((4, n, 9, 0, 8, 32768))
     CASES.append((0, n, 1, 0, 8, 65536))
     CASES.append((4, n, 3, 0, 8, 32768))
+    CASES.append((1, n, 0, 0, 8, 65536))
+for mem in (1, 5, 9):
+    CASES.append((4, 300000, 0, 0, mem, 131072))
+    CASES.append((1, (1 << 20) + 70000, 0, 4, mem, 1 << 20))
 
 
 @pytest.mark.parametrize("kind,n,level,strategy,mem,chunk", CASES)
@@ -150,7 +154,8 @@ def test_errors_are_loud(engine):
     d = engine.alloc(1 << 16); o = engine.alloc(1 << 17)
     tot = C.c_uint64(0)
     lib = engine.lib
-    assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 0, 0, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
+    assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 10, 0, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
+    assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 0, 3, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
     assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1000, 6, 0, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
     assert lib.zamd_deflate_dev(engine.handle, d.ptr, 1 << 16, 1 << 16, 6, 7, 8, 1, o.ptr, 1 << 17, None, C.byref(tot)) == zlib_amd.Z_STREAM_ERROR
     d.upload(bytes(os.urandom(1 << 16)))

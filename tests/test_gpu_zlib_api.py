@@ -16,10 +16,11 @@ pytestmark = pytest.mark.gpu
 
 def test_compress_of_one_chunk_equals_reference_bytes():
     # inputs of at most one chunk are a single Z_FINISH stream: byte-identical to the reference's compress2
-    for data, level in ((b"hello, hello!", 6), (O.corpus(300000, 0, 1), 6), (O.corpus(1 << 20, 4, 5), 9), (b"", 6), (O.corpus(70000, 3, 4), 4)):
+    for data, level in ((b"hello, hello!", 6), (O.corpus(300000, 0, 1), 6), (O.corpus(1 << 20, 4, 5), 9), (b"", 6), (O.corpus(70000, 3, 4), 4),
+                        (O.corpus(200000, 0, 1), 1), (O.corpus(200000, 1, 9), 0)):
         rc, comp = Z.compress2(data, level)
         assert rc == 0
-        flg = {4: 0x5e, 6: 0x9c, 9: 0xda}[level]
+        flg = {0: 0x01, 1: 0x01, 4: 0x5e, 6: 0x9c, 9: 0xda}[level]
         want = bytes([0x78, flg]) + O.deflate_chunk(data, 0, len(data), level, 0, 8, True) + zlib.adler32(data).to_bytes(4, "big")
         assert comp == want
         assert zlib.decompress(comp) == data

@@ -38,13 +38,14 @@
 #define ZC_END_BLOCK 256
 #define ZC_NO_CORNER 0xffffffffu
 
-enum { ZC_PARSE_SLOW = 0, ZC_PARSE_FAST = 1, ZC_PARSE_RLE = 2, ZC_PARSE_HUFF = 3 };
+enum { ZC_PARSE_SLOW = 0, ZC_PARSE_FAST = 1, ZC_PARSE_RLE = 2, ZC_PARSE_HUFF = 3, ZC_PARSE_STORED = 4 };
 enum { ZC_STRAT_DEFAULT = 0, ZC_STRAT_FILTERED = 1, ZC_STRAT_HUFF = 2, ZC_STRAT_RLE = 3, ZC_STRAT_FIXED = 4 };
 
 /* block flags */
 #define ZC_BF_LAST      1u    /* BFINAL */
 #define ZC_BF_CANSTORE  2u    /* block start still inside the window (deflate.c:1539) */
 #define ZC_BF_IMPLICIT  4u    /* symbols are the literal bytes of the block, no symbol buffer */
+#define ZC_BF_STORED    8u    /* level 0: the block is stored whatever it would cost coded (trees.c:945-948) */
 
 struct ZcParams {
     uint32_t level, strategy, mem_level;
@@ -541,6 +542,35 @@ ZC_HD uint32_t zc_parse_fast(uint32_t dict_len, uint32_t len, uint32_t final_, c
     else if (out.nsym != out.blk_sym0) out.flush(p, 0, w);
     *nsym_out = out.nsym;
     return out.nblk;
+}
+
+/* deflate_stored() (deflate.c:1564-1619), level 0: no symbols, only the block
+ * boundaries.  fill_window tops the window up to 2 * w_size whenever the lookahead
+ * is used up (one deflate call hands over the whole chunk); a block ends at
+ * min(0xffff, pending_buf_size - 5) bytes (:1571-1576, 1597-1603) or as soon as
+ * it spans MAX_DIST (:1607-1609). */
+template <class Blk>
+ZC_HD uint32_t zc_parse_stored(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P, Blk blk)
+{
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    uint32_t max_block = P.lit_bufsize * 4u - 5u;
+    if (max_block > 0xffffu) max_block = 0xffffu;
+    uint32_t p = dict_len, look = 0, bstart = dict_len, nblk = 0;
+    auto flush = [&](uint32_t last) {
+        ZcBlock b; b.sym_start = 0; b.sym_count = 0; b.in_start = bstart; b.in_len = p - bstart;
+        b.flags = ZC_BF_CANSTORE | ZC_BF_STORED | (last ? ZC_BF_LAST : 0u); b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
+        blk(nblk++, b); bstart = p;
+    };
+    for (;;) {
+        if (look <= 1) { w.refill(p); look = w.wend - p; if (look == 0) break; }
+        p += look; look = 0;
+        const uint32_t max_start = bstart + max_block;
+        if (p >= max_start) { look = p - max_start; p = max_start; flush(0); }
+        if (p - bstart >= ZC_MAX_DIST) flush(0);
+    }
+    if (final_) flush(1);
+    else if (p > bstart) flush(0);
+    return nblk;
 }
 
 /* deflate_huff() (deflate.c:1934-1967): every byte a literal, so the block

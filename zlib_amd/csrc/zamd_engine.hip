@@ -394,6 +394,7 @@ __global__ __launch_bounds__(64) void k_parse(ZkJob J)
     GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
     uint32_t nsym = 0, nb;
     if (J.P.parser == ZC_PARSE_HUFF) nb = zc_parse_huff(g.dict_len, g.len, g.final, J.P, blk);
+    else if (J.P.parser == ZC_PARSE_STORED) nb = zc_parse_stored(g.dict_len, g.len, g.final, J.P, blk);
     else if (J.P.parser == ZC_PARSE_RLE) nb = zc_parse_rle(g.dict_len, g.len, g.final, J.P, rec, sym, blk, &nsym);
     else nb = zc_parse_slow(g.dict_len, g.len, g.final, J.P, rec, sym, blk, &nsym);
     if (lane == 0) {
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     ZcBlock *bp = J.blk + (uint64_t)lc * J.P.max_blocks + j;
     ZcBlock b = *bp;
+    if (b.flags & ZC_BF_STORED) return;          /* type 0 already; nothing to count or build */
     const uint8_t *src = J.in + g.dstart;
     const uint32_t *sym = J.sym + (uint64_t)lc * J.P.chunk_size + b.sym_start;
     for (uint32_t i = tid; i < 320; i += ZK_PLAN_THREADS) hist[i] = 0;
@@ -983,14 +985,16 @@ static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint
     static const uint16_t cfg[10][4] = {{0, 0, 0, 0}, {4, 4, 8, 4}, {4, 5, 16, 8}, {4, 6, 32, 32}, {4, 4, 16, 16},
                                         {8, 16, 32, 32}, {8, 16, 128, 128}, {8, 32, 128, 256}, {32, 128, 258, 1024}, {32, 258, 258, 4096}};
     if (level == -1) level = 6;
-    if (level < 1 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9) return ZAMD_STREAM_ERROR;
+    if (level < 0 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9) return ZAMD_STREAM_ERROR;
+    /* level 0 with Z_HUFFMAN_ONLY / Z_RLE pushes blocks beyond the reference's own pending buffer (trees.c:1224) */
+    if (level == 0 && (strategy == ZC_STRAT_HUFF || strategy == ZC_STRAT_RLE)) return ZAMD_STREAM_ERROR;
     if (chunk_size < 32768 || chunk_size % 16384 != 0 || chunk_size > (64u << 20)) return ZAMD_STREAM_ERROR;
     memset(&P, 0, sizeof P);
     P.level = (uint32_t)level; P.strategy = (uint32_t)strategy; P.mem_level = (uint32_t)mem_level;
     P.good = cfg[level][0]; P.lazy = cfg[level][1]; P.nice = cfg[level][2]; P.chain = cfg[level][3];
     P.hash_bits = (uint32_t)mem_level + 7; P.hash_mask = (1u << P.hash_bits) - 1; P.hash_shift = (P.hash_bits + 2) / 3;
     P.lit_bufsize = 1u << (mem_level + 6);
-    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level <= 3 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
+    P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level == 0 ? ZC_PARSE_STORED : level <= 3 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
     P.chunk_size = chunk_size;
     P.max_blocks = max_blocks_for(chunk_size, mem_level);
     return ZAMD_OK;

@@ -280,8 +280,9 @@ int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int mem
     if (memLevel < 1 || memLevel > 9 || method != Z_DEFLATED || windowBits < 8 || windowBits > 15 ||
         level < 0 || level > 9 || strategy < 0 || strategy > Z_FIXED)
         return Z_STREAM_ERROR;
-    // The engine implements the 32 KiB window only, and no stored-only level.
-    if (windowBits != 15 || level == 0) { strm->msg = "parameter not supported by the GPU engine"; return Z_STREAM_ERROR; }
+    // The engine implements the 32 KiB window only; level 0 with Z_HUFFMAN_ONLY / Z_RLE overruns the
+    // reference's own pending buffer (trees.c:1224) and is refused.
+    if (windowBits != 15 || (level == 0 && (strategy == Z_HUFFMAN_ONLY || strategy == Z_RLE))) { strm->msg = "parameter not supported by the GPU engine"; return Z_STREAM_ERROR; }
     void *mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(DState));
     if (mem == Z_NULL) return Z_MEM_ERROR;
     DState *s = new (mem) DState();
@@ -365,7 +366,8 @@ int deflateParams(z_streamp strm, int level, int strategy) {
     DState *s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
     if (level == Z_DEFAULT_COMPRESSION) level = 6;
-    if (level < 1 || level > 9 || strategy < 0 || strategy > Z_FIXED) return Z_STREAM_ERROR;
+    if (level < 0 || level > 9 || strategy < 0 || strategy > Z_FIXED) return Z_STREAM_ERROR;
+    if (level == 0 && (strategy == Z_HUFFMAN_ONLY || strategy == Z_RLE)) return Z_STREAM_ERROR;
     int err = Z_OK;
     if ((level != s->level || strategy != s->strategy) && !s->in.empty()) {
         // Input accepted so far is compressed with the old parameters, as the
