@@ -28,7 +28,7 @@
 #define ZK_HALO      32768u
 #define ZK_WIN_BYTES (ZK_HALO + ZK_TILE + 320u)
 #define ZK_MATCH_THREADS 1024
-#define ZK_PLAN_THREADS  256
+#define ZK_PLAN_THREADS  64                   /* one wave per block: the tree builds are serial, what counts is blocks in flight */
 #define ZK_EMIT_THREADS  256
 #define ZK_STAGE_WORDS   400                  /* 31 + 256*48 + 31 bits */
 
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
         zc_build_tree(lt, 15, true, [](int n) { return zc_static_llen((uint32_t)n); },
                       [](int n) { return n >= 257 ? zc_len_extra((uint32_t)n - 257u) : 0u; }, &o, &s);
         cost[0] = o; cost[1] = s;
-    } else if (tid == 64) {
+    } else if (tid == 32) {
         uint32_t o = 0, s = 0;
         zc_build_tree(dt, 15, true, [](int) { return 5u; },
                       [](int n) { return zc_dist_extra((uint32_t)n); }, &o, &s);
