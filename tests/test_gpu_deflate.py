@@ -94,6 +94,7 @@ def test_full_size_chunks_round_trip_and_sampled_parity(engine):
     out, offs = engine.deflate_chunks(data, level=6, chunk_size=1 << 20)
     assert offs[0] == 0 and all(b > a for a, b in zip(offs, offs[1:])) and offs[-1] == len(out)
     assert zlib.decompress(out, -15) == data                         # one valid raw deflate stream
+    assert engine.inflate_chunks(out, offs, n, chunk_size=1 << 20) == data   # and the GPU's own batch inflate agrees
     for c in range(len(offs) - 2):
         assert out[offs[c + 1] - 4:offs[c + 1]] == b"\x00\x00\xff\xff"  # every non-final chunk ends on a sync marker
     for c in (0, 1, 77, 128, 255):
