@@ -255,3 +255,22 @@ def test_preloaded_under_a_program_linked_against_libz():
     assert "error text: Error -3 while decompressing data: invalid block type" in r.stdout
     checks = [l for l in lines if l.split(":")[0] not in ("runtime version", "error text")]
     assert len(checks) == 5 and all("False" not in l for l in checks), r.stdout
+
+
+def test_false_sync_markers_inside_the_data():
+    # 00 00 FF FF inside stored blocks and inside Huffman-coded data looks like a flush point: the guesses
+    # that start there must not change the result
+    import random
+    rnd = random.Random(5)
+    raw = bytearray(rnd.getrandbits(8) for _ in range(400000))
+    for i in range(0, len(raw) - 8, 997):
+        raw[i:i + 4] = b"\x00\x00\xff\xff"
+    raw = bytes(raw)
+    for level in (0, 1, 6):
+        c = zlib.compressobj(level, zlib.DEFLATED, 15)
+        comp = c.compress(raw[:150000]) + c.flush(zlib.Z_SYNC_FLUSH) + c.compress(raw[150000:]) + c.flush()
+        assert comp.count(b"\x00\x00\xff\xff") > (50 if level == 0 else 1)
+        for in_step in (None, 70000):
+            rc, out, msg, unused, _ = Z.inflate_stream(comp, 15, in_step=in_step, out_step=1 << 20)
+            assert rc == Z.Z_STREAM_END, msg
+            assert out == raw

@@ -632,13 +632,18 @@ int decode_some(z_streamp strm, IState *s) {
     }
     std::vector<zamd_inflate_seg> segs;
     const uint64_t end_bits = s->in.size() * 8ull;
-    auto add = [&](uint64_t bit, uint32_t win) {
+    // A candidate is a guess: what starts there may be the middle of a stored block, so its
+    // wavefront gets a bounded amount of input and output (a real segment that is longer is
+    // continued from where it stopped, as the known start of the next attempt).
+    const uint64_t spec_bits = 96ull << 23, spec_out = 96ull << 20;
+    auto add = [&](uint64_t bit, uint32_t win, bool guess) {
         zamd_inflate_seg g; memset(&g, 0, sizeof g);
-        g.in_bit = bit; g.in_end_bit = end_bits; g.out_off = 0; g.out_cap = ~0ull >> 2; g.win_avail = win; g.mode = ZAMD_INF_SYNCSTOP;
+        g.in_bit = bit; g.in_end_bit = (guess && bit + spec_bits < end_bits) ? bit + spec_bits : end_bits;
+        g.out_off = 0; g.out_cap = guess ? spec_out : (~0ull >> 2); g.win_avail = win; g.mode = ZAMD_INF_SYNCSTOP;
         segs.push_back(g);
     };
-    add(s->bit_off, (uint32_t)s->hist.size());
-    for (uint64_t c : s->cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST);
+    add(s->bit_off, (uint32_t)s->hist.size(), false);
+    for (uint64_t c : s->cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST, true);
 
     std::lock_guard<std::mutex> lk(g_gpu.mu);
     zamd_engine *e = engine_locked();
@@ -669,7 +674,8 @@ int decode_some(z_streamp strm, IState *s) {
             produced += g.out_len; end_bit = g.end_bit;
         }
         if (g.status >= 16) {
-            // valid blocks in front of the error are delivered first; the error comes back on the next attempt
+            // valid blocks in front of the error are delivered first; the error (or, for a guess that hit
+            // its output bound, the rest of the segment) comes back on the next attempt
             if (chain.empty()) return ibad(strm, s, zamd_inflate_message(g.status));
             break;
         }
