@@ -3,9 +3,9 @@
 
 One step = one pass of the engine over this rank's shard of the synthetic corpus
 (inputs already resident in HBM): level-6 (deflate_slow) chunked raw deflate,
-1 MiB chunks, 32 KiB dictionary priming, Z_SYNC_FLUSH per chunk — BASELINE.json
-configs[2] cut to its per-GPU share (8 GiB of the 64 GiB mixed corpus per GPU,
-weak scaling).  With N > 1 ranks every rank compresses its contiguous chunk
+1 MiB chunks, 32 KiB dictionary priming, Z_SYNC_FLUSH per chunk — the 64 GiB
+mixed-corpus configuration cut to its per-GPU share (8 GiB per GPU, weak
+scaling), followed by the batch inflate of what was produced.  With N > 1 ranks every rank compresses its contiguous chunk
 range and the per-chunk lengths are all-gathered over RCCL and scanned into
 global output offsets inside the timed step.
 
@@ -25,10 +25,10 @@ CHUNK = 1 << 20
 PIECE = 16 << 20
 WORKLOADS = {
     # name: (corpus kind, seed, level, strategy, mem_level)
-    "l6_mixed": (4, 5, 6, 0, 8),      # BASELINE configs[2], the metric's "deflate GB/s @level 6"
-    "l9_lowent": (2, 3, 9, 0, 8),     # configs[3]
+    "l6_mixed": (4, 5, 6, 0, 8),      # the headline configuration: "deflate GB/s @level 6"
+    "l9_lowent": (2, 3, 9, 0, 8),
     "l6_text": (0, 1, 6, 0, 8),
-    "l1_text": (0, 1, 1, 0, 8),       # configs[1]: deflate_fast
+    "l1_text": (0, 1, 1, 0, 8),       # deflate_fast
 }
 
 

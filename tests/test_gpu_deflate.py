@@ -86,7 +86,7 @@ def test_pathological_inputs(engine):
 
 
 def test_full_size_chunks_round_trip_and_sampled_parity(engine):
-    """BASELINE-sized chunks (1 MiB, 256 of them): size-independent properties over the
+    """Benchmark-sized chunks (1 MiB, 256 of them): size-independent properties over the
     whole stream, byte parity with the oracle on sampled chunks."""
     n = 256 << 20
     import zlib_amd
