@@ -77,6 +77,12 @@ int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_
                            int level, int strategy, int mem_level, int finish,
                            void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out);
 
+/* deflateTune (deflate.c:531-547) for the following deflate calls of this engine:
+ * good_length, max_lazy (max_insert_length at levels 1-3), nice_length, max_chain
+ * instead of the level's table values; all four 0 = back to the table.  max_chain
+ * must be >= 1, and <= 64 at levels 1-3. */
+int zamd_engine_tune(zamd_engine *e, int good_length, int max_lazy, int nice_length, int max_chain);
+
 /*
  * Per-chunk checksums of a device buffer: adler32 (adler32.c:65) and crc32
  * (crc32.c:204) of every chunk_size slice, each started from the initial value

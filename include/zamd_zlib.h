@@ -113,8 +113,10 @@ int deflateCopy(z_streamp dest, z_streamp source);                              
  * bytes: for other lengths the oldest dictLength % 16 bytes are not matched against
  * (the stream stays valid for the full dictionary, dictid covers all of it). */
 int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength);                 /* :323 */
-/* accepted by the reference, not supported by the chunked engine: return Z_STREAM_ERROR */
+/* Holds for all input compressed after the call (input still buffered included) until
+ * deflateReset or a level change.  max_chain must be >= 1, and <= 64 at levels 1-3. */
 int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain);     /* :531 */
+/* accepted by the reference, not supported by the chunked engine: returns Z_STREAM_ERROR */
 int deflatePrime(z_streamp strm, int bits, int value);                                              /* :464 */
 
 /* inflate side: inflate.c:104-1512 */

@@ -39,11 +39,13 @@ static void gen(uint8_t *b, size_t n)
     }
 }
 
+static const int *g_tune;   /* deflateTune values for the next reference call, or NULL */
 static size_t ref_chunk(const uint8_t *buf, size_t dict, size_t n, int level, int strat, int mem, int final,
                         uint8_t *out, size_t cap)
 {
     z_stream z; memset(&z, 0, sizeof z);
     if (deflateInit2(&z, level, Z_DEFLATED, -15, mem, strat) != Z_OK) return (size_t)-1;
+    if (g_tune) deflateTune(&z, g_tune[0], g_tune[1], g_tune[2], g_tune[3]);
     if (dict && deflateSetDictionary(&z, buf, (uInt)dict) != Z_OK) { deflateEnd(&z); return (size_t)-1; }
     z.next_in = (Bytef *)(buf + dict); z.avail_in = (uInt)n; z.next_out = out; z.avail_out = (uInt)cap;
     int r = deflate(&z, final ? Z_FINISH : Z_SYNC_FLUSH);
@@ -97,11 +99,17 @@ int main(int argc, char **argv)
         if (rnd() % 2) strat = 0;
         gen(buf, dict + n);
         size_t cap = 2 * max_len + 65536;
+        int tune[4]; g_tune = NULL;
+        if (level > 0 && rnd() % 4 == 0) {        /* deflateTune: chain lengths, lazy limits and nice lengths off the table */
+            static const int lazies[] = {0, 1, 2, 3, 4, 5, 8, 16, 64, 258, 300}, nices[] = {3, 4, 8, 9, 32, 100, 258, 259, 1000}, chains[] = {1, 2, 3, 5, 8, 17, 40, 64, 100, 500};
+            tune[0] = 1 + (int)(rnd() % 40); tune[1] = lazies[rnd() % 11]; tune[2] = nices[rnd() % 9]; tune[3] = chains[rnd() % (level <= 3 ? 8 : 10)];
+            g_tune = tune;
+        }
         int died = 0;
         size_t a = ref_chunk_guarded(buf, dict, n, level, strat, mem, final, o1, cap, &died);
         if (died) { ref_corrupt++; fprintf(stderr, "reference crashed: it=%ld n=%zu L=%d S=%d M=%d\n", it, n, level, strat, mem); continue; }
         zo_trace tr; memset(&tr, 0, sizeof tr);
-        size_t b = zo_deflate_chunk(buf, dict, n, level, strat, mem, 15, final, o2, cap, &tr);
+        size_t b = zo_deflate_chunk_tuned(buf, dict, n, level, strat, mem, 15, final, g_tune, o2, cap, &tr);
         int ok = a == b && a != (size_t)-1 && memcmp(o1, o2, a) == 0;
         /* trace must tile the chunk */
         if (ok && !(level == 0 && tr.n_syms == 0)) { uint32_t pos = (uint32_t)dict; for (size_t i = 0; i < tr.n_syms; i++) { if (tr.syms[i].pos != pos) { ok = 0; break; } pos += tr.syms[i].dist ? tr.syms[i].lc + 3u : 1u; } if (pos != dict + n) ok = 0; }

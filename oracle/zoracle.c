@@ -536,6 +536,14 @@ size_t zo_deflate_chunk(const uint8_t *buf, size_t dict_len, size_t n,
                         int level, int strategy, int mem_level, int wbits,
                         int final, uint8_t *out, size_t out_cap, zo_trace *trace)
 {
+    return zo_deflate_chunk_tuned(buf, dict_len, n, level, strategy, mem_level, wbits, final, NULL, out, out_cap, trace);
+}
+
+/* the same after deflateTune(good_length, max_lazy, nice_length, max_chain) (deflate.c:531-547); tune == NULL: table values */
+size_t zo_deflate_chunk_tuned(const uint8_t *buf, size_t dict_len, size_t n,
+                              int level, int strategy, int mem_level, int wbits,
+                              int final, const int *tune, uint8_t *out, size_t out_cap, zo_trace *trace)
+{
     if (level == -1) level = 6;                                    /* deflate.c:258 */
     if (level < 0 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9 ||
         wbits < 9 || wbits > 15 || dict_len > (1u << wbits) || dict_len + n > 0xfffffff0u)
@@ -549,6 +557,7 @@ size_t zo_deflate_chunk(const uint8_t *buf, size_t dict_len, size_t n,
     s->hshift = (s->hbits + MINM - 1) / MINM;
     s->lit_bufsize = 1u << (mem_level + 6);                                    /* deflate.c:299 */
     s->good = cfg[level].good; s->lazy = cfg[level].lazy; s->nice = cfg[level].nice; s->chain = cfg[level].chain;
+    if (tune) { s->good = (uint32_t)tune[0]; s->lazy = (uint32_t)tune[1]; s->nice = (uint32_t)tune[2]; s->chain = (uint32_t)tune[3]; }
     s->head = (uint32_t *)calloc((size_t)1 << s->hbits, sizeof(uint32_t));
     s->prev = (uint32_t *)calloc(s->wsize, sizeof(uint32_t));
     s->d_buf = (uint16_t *)malloc(s->lit_bufsize * sizeof(uint16_t));

@@ -60,6 +60,10 @@ void zo_trace_free(zo_trace *t);
  * of output bytes, or (size_t)-1 if out_cap is too small or a parameter is out
  * of range.  `trace` may be NULL.
  */
+size_t zo_deflate_chunk_tuned(const uint8_t *buf, size_t dict_len, size_t n,
+                              int level, int strategy, int mem_level, int wbits,
+                              int final, const int *tune /* good, lazy, nice, chain or NULL */,
+                              uint8_t *out, size_t out_cap, zo_trace *trace);
 size_t zo_deflate_chunk(const uint8_t *buf, size_t dict_len, size_t n,
                         int level, int strategy, int mem_level, int wbits,
                         int final, uint8_t *out, size_t out_cap, zo_trace *trace);

@@ -182,3 +182,25 @@ def test_shard_entry_point_with_a_short_head_dictionary(engine, head):
         ln = min(chunk, len(data) - start)
         want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, 6, 0, 8, c == nch - 1)
     assert out == want and offs[-1] == len(want)
+
+
+@pytest.mark.parametrize("level,tune", [(6, (4, 4, 16, 8)), (6, (8, 258, 258, 300)), (9, (32, 16, 100, 2000)), (4, (1, 0, 3, 1)),
+                                        (5, (40, 300, 1000, 17)), (1, (4, 8, 32, 64)), (2, (4, 3, 9, 1)), (3, (4, 258, 258, 40))])
+def test_tuned_parameters_match_the_oracle(engine, level, tune):
+    """deflateTune values instead of the level's table (deflate.c:531-547)."""
+    data = O.corpus(3 * 65536 + 1234, 4, 61) + O.corpus(100000, 0, 62)
+    chunk = 65536
+    engine.tune(*tune)
+    try:
+        out, offs = engine.deflate_chunks(data, level=level, chunk_size=chunk)
+    finally:
+        engine.tune()
+    want = b""
+    nch = (len(data) + chunk - 1) // chunk
+    for c in range(nch):
+        start = c * chunk
+        dl, ln = min(start, 32768), min(chunk, len(data) - start)
+        want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, level, 0, 8, c == nch - 1, tune=tune)
+    assert out == want
+    plain, _ = engine.deflate_chunks(data, level=level, chunk_size=chunk)
+    assert plain == O.deflate_chunked(data, chunk, level, 0, 8)[0]        # and the table values are back

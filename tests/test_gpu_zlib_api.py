@@ -200,6 +200,43 @@ def test_params_change_mid_stream():
     assert l.deflateEnd(C.byref(s)) == Z.Z_OK
 
 
+def test_tuned_stream_equals_the_tuned_reference():
+    """deflateTune (deflate.c:531-547): values hold until deflateReset or a level change."""
+    data = O.corpus(400000, 4, 77)
+    l = Z.lib()
+    s = Z.ZStream()
+    src = C.create_string_buffer(data, len(data))
+    cap = len(data) + 4096
+    obuf = C.create_string_buffer(cap)
+
+    def one_shot():
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(data), C.addressof(obuf), cap
+        s.total_out = 0
+        assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+        return obuf.raw[:s.total_out]
+
+    assert l.deflateInit2_(C.byref(s), 6, 8, -15, 8, 0, Z.VERSION, Z.SZ) == 0
+    tune = (4, 5, 24, 12)
+    assert l.deflateTune(C.byref(s), *tune) == Z.Z_OK
+    tuned = one_shot()
+    assert tuned == O.deflate_chunk(data, 0, len(data), 6, 0, 8, True, tune=tune)
+    plain = O.deflate_chunk(data, 0, len(data), 6, 0, 8, True)
+    assert tuned != plain
+    assert l.deflateReset(C.byref(s)) == Z.Z_OK                 # back to the level's table
+    assert one_shot() == plain
+    assert l.deflateReset(C.byref(s)) == Z.Z_OK
+    assert l.deflateTune(C.byref(s), *tune) == Z.Z_OK
+    assert l.deflateParams(C.byref(s), 7, 0) == Z.Z_OK          # a new level brings its own values
+    assert one_shot() == O.deflate_chunk(data, 0, len(data), 7, 0, 8, True)
+    assert l.deflateReset(C.byref(s)) == Z.Z_OK
+    assert l.deflateTune(C.byref(s), 4, 4, 8, 0) == Z.Z_STREAM_ERROR       # no chain budget
+    assert l.deflateParams(C.byref(s), 1, 0) == Z.Z_OK
+    assert l.deflateTune(C.byref(s), 4, 4, 8, 65) == Z.Z_STREAM_ERROR      # levels 1-3: at most 64
+    assert l.deflateTune(C.byref(s), 4, 6, 8, 64) == Z.Z_OK
+    assert one_shot() == O.deflate_chunk(data, 0, len(data), 1, 0, 8, True, tune=(4, 6, 8, 64))
+    assert l.deflateEnd(C.byref(s)) == Z.Z_OK
+
+
 def _deflate_with_dict(data, d, level=6, wbits=15):
     l = Z.lib()
     s = Z.ZStream()

@@ -866,6 +866,7 @@ struct zamd_engine {
     hipEvent_t ev_scan[ZE_STREAMS], ev_init;
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
+    int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
     uint64_t ws_budget;
     uint64_t *d_total; uint32_t *d_err;
     uint64_t *d_off_own; uint64_t d_off_cap;
@@ -970,6 +971,18 @@ static uint32_t max_blocks_for(uint32_t chunk_size, int mem_level)
     return (chunk_size + lim - 1) / lim + 2;
 }
 
+extern "C" int zamd_engine_tune(zamd_engine *e, int good_length, int max_lazy, int nice_length, int max_chain)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    if (good_length == 0 && max_lazy == 0 && nice_length == 0 && max_chain == 0) { e->tuned = 0; return ZAMD_OK; }
+    /* a chain budget of 0 makes the reference's loop counter wrap; nothing sensible to be exact against */
+    if (good_length < 0 || max_lazy < 0 || nice_length < 0 || max_chain < 1 || max_chain > 65535 || max_lazy > 65535 || nice_length > 65535 || good_length > 65535)
+        return ZAMD_STREAM_ERROR;
+    e->tune[0] = (uint32_t)good_length; e->tune[1] = (uint32_t)max_lazy; e->tune[2] = (uint32_t)nice_length; e->tune[3] = (uint32_t)max_chain;
+    e->tuned = 1;
+    return ZAMD_OK;
+}
+
 extern "C" uint64_t zamd_deflate_bound(uint64_t n, uint32_t chunk_size, int mem_level)
 {
     if (chunk_size == 0 || mem_level < 1 || mem_level > 9) return 0;
@@ -1022,6 +1035,11 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     ZcParams P;
     int rc = fill_params(P, level, strategy, mem_level, chunk_size);
     if (rc) return rc;
+    if (e->tuned && level != 0) {
+        P.good = e->tune[0]; P.lazy = e->tune[1]; P.nice = e->tune[2]; P.chain = e->tune[3];
+        /* levels 1-3 compare the candidates of a walk one per lane */
+        if (P.parser == ZC_PARSE_FAST && P.chain > 64) return ZAMD_STREAM_ERROR;
+    }
     out_cap &= ~15ull;
     HIPCHK(hipSetDevice(e->device));
     const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;

@@ -99,6 +99,7 @@ struct DState {
     uint64_t batch_bytes;
     gz_headerp gzhead;
     bool trailer_done, have_dict;
+    bool tuned; int tune[4];           // deflateTune values, kept until deflateReset or a level change
     uint32_t dictid;
     uint32_t hist_len;                 // bytes of history kept in `hist` (== HIST once warm)
     uint64_t since_reset;              // input bytes compressed since the last history reset
@@ -193,9 +194,13 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     if (head) rc = zamd_dev_upload(e, g_gpu.d_in + (HIST - head), s->hist.data() + (s->hist_len - head), head);
     if (rc == 0 && n) rc = zamd_dev_upload(e, g_gpu.d_in + HIST, src, n);
     uint64_t total = 0;
-    if (rc == 0)
-        rc = zamd_deflate_shard_dev(e, g_gpu.d_in + HIST, n, head, s->chunk_size, s->level, s->strategy,
-                                    s->mem_level, finish, g_gpu.d_out, bound, nullptr, &total);
+    if (rc == 0) {
+        if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+        if (rc == 0)
+            rc = zamd_deflate_shard_dev(e, g_gpu.d_in + HIST, n, head, s->chunk_size, s->level, s->strategy,
+                                        s->mem_level, finish, g_gpu.d_out, bound, nullptr, &total);
+        if (s->tuned) zamd_engine_tune(e, 0, 0, 0, 0);      // the engine is shared by all streams
+    }
     if (rc == 0 && s->wrap && n) {
         uint32_t v = (uint32_t)strm->adler;
         rc = s->wrap == 2 ? zamd_crc32_dev(e, v, g_gpu.d_in + HIST, n, &v)
@@ -320,6 +325,7 @@ int deflateReset(z_streamp strm) {
         DState *s = dstate(strm);
         s->in.clear();
         reset_history(s);
+        s->tuned = false;                      // lm_init takes the level's table again, deflate.c:1108-1111
     }
     return ret;
 }
@@ -353,9 +359,20 @@ int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
     s->hist_len = keep;
     return Z_OK;
 }
-int deflateTune(z_streamp strm, int, int, int, int) {
-    if (strm) strm->msg = "deflateTune is not supported by the GPU engine";
-    return Z_STREAM_ERROR;
+int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain) {    // deflate.c:531-547
+    DState *s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    // The values hold for input compressed from now on, buffered input included.  A chain budget
+    // below 1 has no defined meaning in the reference's loop; levels 1-3 walk at most 64 candidates.
+    if (good_length < 0 || max_lazy < 0 || nice_length < 0 || max_chain < 1 || good_length > 65535 ||
+        max_lazy > 65535 || nice_length > 65535 || max_chain > 65535 ||
+        (s->level >= 1 && s->level <= 3 && max_chain > 64)) {
+        strm->msg = "deflateTune values not supported by the GPU engine";
+        return Z_STREAM_ERROR;
+    }
+    s->tune[0] = good_length; s->tune[1] = max_lazy; s->tune[2] = nice_length; s->tune[3] = max_chain;
+    s->tuned = true;
+    return Z_OK;
 }
 int deflatePrime(z_streamp strm, int, int) {
     if (strm) strm->msg = "deflatePrime is not supported by the GPU engine";
@@ -378,6 +395,7 @@ int deflateParams(z_streamp strm, int level, int strategy) {
         if (err != Z_OK) return err;
         if (strm->next_out != Z_NULL) flush_pending(strm, s);
     }
+    if (level != s->level) s->tuned = false;   // a new level brings its own table values, deflate.c:519-525
     s->level = level;
     s->strategy = strategy;
     return err;
