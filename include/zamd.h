@@ -83,6 +83,11 @@ int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_
  * must be >= 1, and <= 64 at levels 1-3. */
 int zamd_engine_tune(zamd_engine *e, int good_length, int max_lazy, int nice_length, int max_chain);
 
+/* deflatePrime (deflate.c:464-487) for the next deflate call of this engine only: `bits`
+ * (0..7) low bits of `value` precede the first block of the call's first chunk, which
+ * starts inside output byte 0 as it does in the reference after deflatePrime. */
+int zamd_engine_prime(zamd_engine *e, int bits, int value);
+
 /*
  * Per-chunk checksums of a device buffer: adler32 (adler32.c:65) and crc32
  * (crc32.c:204) of every chunk_size slice, each started from the initial value

@@ -116,8 +116,7 @@ int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
 /* Holds for all input compressed after the call (input still buffered included) until
  * deflateReset or a level change.  max_chain must be >= 1, and <= 64 at levels 1-3. */
 int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain);     /* :531 */
-/* accepted by the reference, not supported by the chunked engine: returns Z_STREAM_ERROR */
-int deflatePrime(z_streamp strm, int bits, int value);                                              /* :464 */
+int deflatePrime(z_streamp strm, int bits, int value);              /* :464; bits 0..32 */
 
 /* inflate side: inflate.c:104-1512 */
 int inflateInit_(z_streamp strm, const char *version, int stream_size);                             /* :222 */
@@ -135,7 +134,9 @@ int inflateSyncPoint(z_streamp strm);                                           
 int inflateCopy(z_streamp dest, z_streamp source);                                                  /* :1438 */
 int inflateUndermine(z_streamp strm, int subvert);                                                  /* :1485 */
 long inflateMark(z_streamp strm);                                                                   /* :1502 */
-int inflatePrime(z_streamp strm, int bits, int value);            /* :230; not supported: Z_STREAM_ERROR */
+/* On deflate data (raw streams, or once the wrapper header is through) before any input of
+ * it has been handed over; Z_STREAM_ERROR otherwise. */
+int inflatePrime(z_streamp strm, int bits, int value);                                              /* :230 */
 
 /* one-shot utilities: compress.c:22-80, uncompr.c:24-59 */
 int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen);

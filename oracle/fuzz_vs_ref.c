@@ -40,12 +40,14 @@ static void gen(uint8_t *b, size_t n)
 }
 
 static const int *g_tune;   /* deflateTune values for the next reference call, or NULL */
+static int g_prime_bits, g_prime_val;   /* deflatePrime in front of the next reference call */
 static size_t ref_chunk(const uint8_t *buf, size_t dict, size_t n, int level, int strat, int mem, int final,
                         uint8_t *out, size_t cap)
 {
     z_stream z; memset(&z, 0, sizeof z);
     if (deflateInit2(&z, level, Z_DEFLATED, -15, mem, strat) != Z_OK) return (size_t)-1;
     if (g_tune) deflateTune(&z, g_tune[0], g_tune[1], g_tune[2], g_tune[3]);
+    if (g_prime_bits) deflatePrime(&z, g_prime_bits, g_prime_val);
     if (dict && deflateSetDictionary(&z, buf, (uInt)dict) != Z_OK) { deflateEnd(&z); return (size_t)-1; }
     z.next_in = (Bytef *)(buf + dict); z.avail_in = (uInt)n; z.next_out = out; z.avail_out = (uInt)cap;
     int r = deflate(&z, final ? Z_FINISH : Z_SYNC_FLUSH);
@@ -105,15 +107,17 @@ int main(int argc, char **argv)
             tune[0] = 1 + (int)(rnd() % 40); tune[1] = lazies[rnd() % 11]; tune[2] = nices[rnd() % 9]; tune[3] = chains[rnd() % (level <= 3 ? 8 : 10)];
             g_tune = tune;
         }
+        g_prime_bits = 0; g_prime_val = 0;
+        if (rnd() % 6 == 0) { g_prime_bits = 1 + (int)(rnd() % 7); g_prime_val = (int)(rnd() & 0xffff); }
         int died = 0;
         size_t a = ref_chunk_guarded(buf, dict, n, level, strat, mem, final, o1, cap, &died);
         if (died) { ref_corrupt++; fprintf(stderr, "reference crashed: it=%ld n=%zu L=%d S=%d M=%d\n", it, n, level, strat, mem); continue; }
         zo_trace tr; memset(&tr, 0, sizeof tr);
-        size_t b = zo_deflate_chunk_tuned(buf, dict, n, level, strat, mem, 15, final, g_tune, o2, cap, &tr);
+        size_t b = zo_deflate_chunk_primed(buf, dict, n, level, strat, mem, 15, final, g_tune, g_prime_bits, g_prime_val, o2, cap, &tr);
         int ok = a == b && a != (size_t)-1 && memcmp(o1, o2, a) == 0;
         /* trace must tile the chunk */
         if (ok && !(level == 0 && tr.n_syms == 0)) { uint32_t pos = (uint32_t)dict; for (size_t i = 0; i < tr.n_syms; i++) { if (tr.syms[i].pos != pos) { ok = 0; break; } pos += tr.syms[i].dist ? tr.syms[i].lc + 3u : 1u; } if (pos != dict + n) ok = 0; }
-        if (ok) {   /* inflate with the oracle's decoder */
+        if (ok && !g_prime_bits) {   /* inflate with the oracle's decoder */
             size_t used = 0, made = 0; const char *msg = 0;
             int rc = zo_inflate_raw(o2, b, buf, dict, back, n, &used, &made, &msg, !final);
             if (rc != 0 || made != n || used != b || memcmp(back, buf + dict, n)) { ok = 0; fprintf(stderr, "inflate rc=%d made=%zu/%zu used=%zu/%zu msg=%s\n", rc, made, n, used, b, msg ? msg : "-"); }
@@ -125,6 +129,7 @@ int main(int argc, char **argv)
             z_stream iz; memset(&iz, 0, sizeof iz); inflateInit2(&iz, -15);
             if (dict) inflateSetDictionary(&iz, buf, (uInt)dict);
             iz.next_in = o1; iz.avail_in = (uInt)a; iz.next_out = back; iz.avail_out = (uInt)n;
+            if (g_prime_bits && a) { inflatePrime(&iz, 8 - g_prime_bits, o1[0] >> g_prime_bits); iz.next_in++; iz.avail_in--; }
             int ir = inflate(&iz, Z_SYNC_FLUSH);
             int self_ok = (ir == Z_OK || ir == Z_STREAM_END || ir == Z_BUF_ERROR) && iz.total_out == n && memcmp(back, buf + dict, n) == 0;
             inflateEnd(&iz);

@@ -544,6 +544,17 @@ size_t zo_deflate_chunk_tuned(const uint8_t *buf, size_t dict_len, size_t n,
                               int level, int strategy, int mem_level, int wbits,
                               int final, const int *tune, uint8_t *out, size_t out_cap, zo_trace *trace)
 {
+    return zo_deflate_chunk_primed(buf, dict_len, n, level, strategy, mem_level, wbits, final, tune, 0, 0, out, out_cap, trace);
+}
+
+/* the same with prime_bits (0..7) bits of prime_val already waiting in the bit buffer, as deflatePrime
+ * leaves them (deflate.c:464-487): the first block starts behind them */
+size_t zo_deflate_chunk_primed(const uint8_t *buf, size_t dict_len, size_t n,
+                               int level, int strategy, int mem_level, int wbits,
+                               int final, const int *tune, int prime_bits, int prime_val,
+                               uint8_t *out, size_t out_cap, zo_trace *trace)
+{
+    if (prime_bits < 0 || prime_bits > 7) return (size_t)-1;
     if (level == -1) level = 6;                                    /* deflate.c:258 */
     if (level < 0 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9 ||
         wbits < 9 || wbits > 15 || dict_len > (1u << wbits) || dict_len + n > 0xfffffff0u)
@@ -566,6 +577,7 @@ size_t zo_deflate_chunk_tuned(const uint8_t *buf, size_t dict_len, size_t n,
     s->out = out; s->out_cap = out_cap; s->tr = trace;
     if (trace) s->tr_sym_base = trace->n_syms;
     reset_block(s);
+    if (prime_bits) put_bits(s, (unsigned)prime_val & ((1u << prime_bits) - 1u), prime_bits);
 
     /* deflateSetDictionary(): deflate.c:323-389.  All dictionary strings with
      * three bytes available are inserted; the last (up to) two are deferred. */

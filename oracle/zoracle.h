@@ -64,6 +64,11 @@ size_t zo_deflate_chunk_tuned(const uint8_t *buf, size_t dict_len, size_t n,
                               int level, int strategy, int mem_level, int wbits,
                               int final, const int *tune /* good, lazy, nice, chain or NULL */,
                               uint8_t *out, size_t out_cap, zo_trace *trace);
+/* ... and with prime_bits (0..7) low bits of prime_val in front of the first block (deflatePrime, deflate.c:464-487) */
+size_t zo_deflate_chunk_primed(const uint8_t *buf, size_t dict_len, size_t n,
+                               int level, int strategy, int mem_level, int wbits,
+                               int final, const int *tune, int prime_bits, int prime_val,
+                               uint8_t *out, size_t out_cap, zo_trace *trace);
 size_t zo_deflate_chunk(const uint8_t *buf, size_t dict_len, size_t n,
                         int level, int strategy, int mem_level, int wbits,
                         int final, uint8_t *out, size_t out_cap, zo_trace *trace);

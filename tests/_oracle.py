@@ -41,6 +41,9 @@ def lib():
         l.zo_deflate_chunk_tuned.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.POINTER(Trace)]
         l.zo_deflate_chunk_tuned.restype = C.c_size_t
+        l.zo_deflate_chunk_primed.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Trace)]
+        l.zo_deflate_chunk_primed.restype = C.c_size_t
         l.zo_trace_free.argtypes = [C.POINTER(Trace)]
         l.zo_adler32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]; l.zo_adler32.restype = C.c_uint32
         l.zo_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]; l.zo_crc32.restype = C.c_uint32
@@ -60,14 +63,14 @@ def corpus(n, kind, seed):
     return buf.raw[:n]
 
 
-def deflate_chunk(buf, dict_len, n, level=6, strategy=0, mem_level=8, final=True, want_trace=False, tune=None):
+def deflate_chunk(buf, dict_len, n, level=6, strategy=0, mem_level=8, final=True, want_trace=False, tune=None, prime=(0, 0)):
     """buf = dictionary + chunk bytes.  Returns bytes, or (bytes, syms, blocks) with want_trace."""
     cap = n + n // 4 + 65536
     out = C.create_string_buffer(cap)
     tr = Trace()
     tv = (C.c_int * 4)(*tune) if tune else None
-    r = lib().zo_deflate_chunk_tuned(bytes(buf), dict_len, n, level, strategy, mem_level, 15, int(final), tv, out, cap,
-                                     C.byref(tr) if want_trace else None)
+    r = lib().zo_deflate_chunk_primed(bytes(buf), dict_len, n, level, strategy, mem_level, 15, int(final), tv, prime[0], prime[1],
+                                      out, cap, C.byref(tr) if want_trace else None)
     if r == C.c_size_t(-1).value:
         raise RuntimeError("oracle deflate failed")
     data = out.raw[:r]

@@ -204,3 +204,18 @@ def test_tuned_parameters_match_the_oracle(engine, level, tune):
     assert out == want
     plain, _ = engine.deflate_chunks(data, level=level, chunk_size=chunk)
     assert plain == O.deflate_chunked(data, chunk, level, 0, 8)[0]        # and the table values are back
+
+
+@pytest.mark.parametrize("level,kind,bits", [(6, 4, 3), (6, 1, 5), (1, 0, 7), (0, 0, 1), (9, 2, 4), (6, 4, 0)])
+def test_primed_bits_shift_the_first_chunk_only(engine, level, kind, bits):
+    """deflatePrime residue (deflate.c:464-487): the call's first chunk starts inside byte 0."""
+    data = O.corpus(2 * 65536 + 999, kind, 71)
+    chunk = 65536
+    engine.prime(bits, 0x5a)
+    out, offs = engine.deflate_chunks(data, level=level, chunk_size=chunk)
+    want = O.deflate_chunk(data[:chunk], 0, chunk, level, 0, 8, False, prime=(bits, 0x5a))
+    want += O.deflate_chunk(data[chunk - 32768:2 * chunk], 32768, chunk, level, 0, 8, False)
+    want += O.deflate_chunk(data[2 * chunk - 32768:], 32768, 999, level, 0, 8, True)
+    assert out == want
+    again, _ = engine.deflate_chunks(data, level=level, chunk_size=chunk)      # one call only
+    assert again == O.deflate_chunked(data, chunk, level, 0, 8)[0]

@@ -311,3 +311,69 @@ def test_false_sync_markers_inside_the_data():
             rc, out, msg, unused, _ = Z.inflate_stream(comp, 15, in_step=in_step, out_step=1 << 20)
             assert rc == Z.Z_STREAM_END, msg
             assert out == raw
+
+
+def test_inflate_prime_starts_inside_a_byte():
+    """inflatePrime (inflate.c:230-250) as examples/zran.c:296-300 uses it: the stream starts at a bit
+    inside a byte whose upper bits are handed over first."""
+    data = O.corpus(300000, 4, 91)
+    l = Z.lib()
+    for k in (1, 3, 7):
+        shifted = O.deflate_chunk(data, 0, len(data), 6, 0, 8, True, prime=(k, 0x7f))    # k foreign bits in front
+        s = Z.ZStream()
+        assert l.inflateInit2_(C.byref(s), -15, Z.VERSION, Z.SZ) == 0
+        if k == 3:      # in two portions
+            assert l.inflatePrime(C.byref(s), 2, (shifted[0] >> k) & 3) == Z.Z_OK
+            assert l.inflatePrime(C.byref(s), 8 - k - 2, shifted[0] >> (k + 2)) == Z.Z_OK
+        else:
+            assert l.inflatePrime(C.byref(s), 8 - k, shifted[0] >> k) == Z.Z_OK
+        src = C.create_string_buffer(shifted[1:], len(shifted) - 1)
+        obuf = C.create_string_buffer(len(data) + 16)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(shifted) - 1, C.addressof(obuf), len(data) + 16
+        assert l.inflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+        assert obuf.raw[:s.total_out] == data
+        assert l.inflatePrime(C.byref(s), 17, 0) == Z.Z_STREAM_ERROR
+        assert l.inflateEnd(C.byref(s)) == Z.Z_OK
+    # a wrapped stream takes no bits in front of its header
+    s = Z.ZStream()
+    assert l.inflateInit2_(C.byref(s), 15, Z.VERSION, Z.SZ) == 0
+    assert l.inflatePrime(C.byref(s), 3, 1) == Z.Z_STREAM_ERROR
+    assert l.inflatePrime(C.byref(s), -1, 0) == Z.Z_OK
+    assert l.inflateEnd(C.byref(s)) == Z.Z_OK
+
+
+def test_deflate_prime_puts_bits_in_front():
+    """deflatePrime (deflate.c:464-487): whole bytes go out at once, the rest shifts the first block."""
+    data = O.corpus(200000, 4, 93)
+    l = Z.lib()
+    for bits, value in ((3, 5), (11, 0x5a5), (8, 0xc3), (16, 0xbeef)):
+        s = Z.ZStream()
+        assert l.deflateInit2_(C.byref(s), 6, 8, -15, 8, 0, Z.VERSION, Z.SZ) == 0
+        assert l.deflatePrime(C.byref(s), bits, value) == Z.Z_OK
+        pend, pbits = C.c_uint(0), C.c_int(0)
+        assert l.deflatePending(C.byref(s), C.byref(pend), C.byref(pbits)) == Z.Z_OK
+        assert (pend.value, pbits.value) == (bits // 8, bits % 8)
+        src = C.create_string_buffer(data, len(data))
+        cap = len(data) + 4096
+        obuf = C.create_string_buffer(cap)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(data), C.addressof(obuf), cap
+        assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+        out = obuf.raw[:s.total_out]
+        assert l.deflateEnd(C.byref(s)) == Z.Z_OK
+        whole, rest = bits // 8, bits % 8
+        want = (value & ((1 << (8 * whole)) - 1)).to_bytes(whole, "little") + \
+            O.deflate_chunk(data, 0, len(data), 6, 0, 8, True, prime=(rest, value >> (8 * whole)))
+        assert out == want
+        # and the reader's counterpart takes it back
+        s = Z.ZStream()
+        assert l.inflateInit2_(C.byref(s), -15, Z.VERSION, Z.SZ) == 0
+        body = out[whole:]
+        if rest:
+            assert l.inflatePrime(C.byref(s), 8 - rest, body[0] >> rest) == Z.Z_OK
+            body = body[1:]
+        src = C.create_string_buffer(body, len(body))
+        back = C.create_string_buffer(len(data) + 16)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(body), C.addressof(back), len(data) + 16
+        assert l.inflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+        assert back.raw[:s.total_out] == data
+        assert l.inflateEnd(C.byref(s)) == Z.Z_OK

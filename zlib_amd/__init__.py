@@ -59,6 +59,8 @@ def load_library() -> C.CDLL:
     lib.zamd_deflate_shard_dev.restype = i32
     lib.zamd_engine_tune.argtypes = [vp, i32, i32, i32, i32]
     lib.zamd_engine_tune.restype = i32
+    lib.zamd_engine_prime.argtypes = [vp, i32, i32]
+    lib.zamd_engine_prime.restype = i32
     lib.zamd_checksums_dev.argtypes = [vp, vp, u64, u32, vp, vp]
     lib.zamd_checksums_dev.restype = i32
     lib.zamd_adler32_dev.argtypes = [vp, u32, vp, u64, C.POINTER(u32)]
@@ -189,6 +191,10 @@ class Engine:
     def tune(self, good_length: int = 0, max_lazy: int = 0, nice_length: int = 0, max_chain: int = 0) -> None:
         """deflateTune for the following deflate calls; no arguments = back to the level's table."""
         _chk(self.lib.zamd_engine_tune(self.handle, good_length, max_lazy, nice_length, max_chain), "zamd_engine_tune")
+
+    def prime(self, bits: int, value: int) -> None:
+        """deflatePrime for the next deflate call: `bits` (0..7) bits of `value` in front of its first block."""
+        _chk(self.lib.zamd_engine_prime(self.handle, bits, value), "zamd_engine_prime")
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

@@ -819,9 +819,9 @@ ZC_HD void zc_plan_block(ZcTree<ZC_L_CODES> &lt, ZcTree<ZC_D_CODES> &dt, ZcTree<
  * a non-final chunk ends with the empty stored block of Z_SYNC_FLUSH
  * (deflate.c:926-927), a final one is padded by bi_windup (trees.c:996-1001). */
 template <class BlkAt>
-ZC_HD uint64_t zc_layout_chunk(BlkAt blk_at, uint32_t nblk, uint32_t final_, uint64_t *sync_bit_off)
+ZC_HD uint64_t zc_layout_chunk(BlkAt blk_at, uint32_t nblk, uint32_t final_, uint64_t *sync_bit_off, uint32_t start_bit = 0)
 {
-    uint64_t bit = 0;
+    uint64_t bit = start_bit;      /* bits deflatePrime left in the bit buffer (deflate.c:464-487) */
     for (uint32_t i = 0; i < nblk; i++) {
         ZcBlock *b = blk_at(i);
         b->bit_off = bit;

@@ -37,6 +37,7 @@ enum { ZE_CHAIN_ORDER = 1, ZE_BLOCK_OVERFLOW = 2, ZE_OUT_OVERFLOW = 4, ZE_INFLAT
 struct ZkJob {
     const uint8_t *in; uint64_t n;
     uint64_t chunk0; uint32_t nchunks; int finish; uint32_t head;
+    uint32_t prime_bits, prime_val;  /* deflatePrime bits in front of the call's first chunk */
     ZcParams P;
     uint16_t *pdist; uint64_t pdist_base, pdist_len;
     uint2 *rec; uint64_t rec_base;
@@ -627,7 +628,9 @@ __global__ void k_layout(ZkJob J)
     ZcBlock *base = J.blk + (uint64_t)lc * J.P.max_blocks;
     uint64_t sync = 0;
     /* a non-final chunk that is the last of a call without finish still ends on a sync marker */
-    J.chunk_bytes[lc] = zc_layout_chunk([&](uint32_t i) { return base + i; }, J.nblk[lc], g.final, &sync);
+    const uint32_t pb = (J.chunk0 + lc == 0) ? J.prime_bits : 0u;
+    if (pb) atomicOr(&J.out32[0], J.prime_val);
+    J.chunk_bytes[lc] = zc_layout_chunk([&](uint32_t i) { return base + i; }, J.nblk[lc], g.final, &sync, pb);
     J.sync_bit[lc] = sync;
 }
 
@@ -866,6 +869,7 @@ struct zamd_engine {
     hipEvent_t ev_scan[ZE_STREAMS], ev_init;
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
+    uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
     int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
     uint64_t ws_budget;
     uint64_t *d_total; uint32_t *d_err;
@@ -983,6 +987,13 @@ extern "C" int zamd_engine_tune(zamd_engine *e, int good_length, int max_lazy, i
     return ZAMD_OK;
 }
 
+extern "C" int zamd_engine_prime(zamd_engine *e, int bits, int value)
+{
+    if (!e || bits < 0 || bits > 7) return ZAMD_STREAM_ERROR;
+    e->prime_bits = (uint32_t)bits; e->prime_val = (uint32_t)value & ((1u << bits) - 1u);
+    return ZAMD_OK;
+}
+
 extern "C" uint64_t zamd_deflate_bound(uint64_t n, uint32_t chunk_size, int mem_level)
 {
     if (chunk_size == 0 || mem_level < 1 || mem_level > 9) return 0;
@@ -1041,6 +1052,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (P.parser == ZC_PARSE_FAST && P.chain > 64) return ZAMD_STREAM_ERROR;
     }
     out_cap &= ~15ull;
+    const uint32_t prime_bits = e->prime_bits, prime_val = e->prime_val;
+    e->prime_bits = 0; e->prime_val = 0;
     HIPCHK(hipSetDevice(e->device));
     const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
     /* batch size from the workspace budget, two batches in flight */
@@ -1076,7 +1089,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         ZkJob J; memset(&J, 0, sizeof J);
         J.in = (const uint8_t *)d_in - head_dict_len; J.n = n + head_dict_len; J.head = head_dict_len; J.chunk0 = (uint64_t)bi * batch;
         J.nchunks = (uint32_t)((total_chunks - J.chunk0) < batch ? (total_chunks - J.chunk0) : batch);
-        J.finish = finish; J.P = P;
+        J.finish = finish; J.P = P; J.prime_bits = prime_bits; J.prime_val = prime_val;
         ZcChunkGeom g0 = zc_geom(J.n, chunk_size, J.chunk0, finish, J.head);
         J.pdist = w.pdist; J.pdist_base = g0.dstart; J.pdist_len = w.pdist_len;
         J.rec = w.rec; J.rec_base = head_dict_len + J.chunk0 * chunk_size;

@@ -99,6 +99,7 @@ struct DState {
     uint64_t batch_bytes;
     gz_headerp gzhead;
     bool trailer_done, have_dict;
+    uint32_t prime_bits, prime_val;    // deflatePrime bits (< 8) that precede the next compressed block
     bool tuned; int tune[4];           // deflateTune values, kept until deflateReset or a level change
     uint32_t dictid;
     uint32_t hist_len;                 // bytes of history kept in `hist` (== HIST once warm)
@@ -196,6 +197,7 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     uint64_t total = 0;
     if (rc == 0) {
         if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+        if (rc == 0 && s->prime_bits) { rc = zamd_engine_prime(e, (int)s->prime_bits, (int)s->prime_val); s->prime_bits = 0; s->prime_val = 0; }
         if (rc == 0)
             rc = zamd_deflate_shard_dev(e, g_gpu.d_in + HIST, n, head, s->chunk_size, s->level, s->strategy,
                                         s->mem_level, finish, g_gpu.d_out, bound, nullptr, &total);
@@ -316,6 +318,7 @@ int deflateResetKeep(z_streamp strm) {
     s->last_flush = Z_NO_FLUSH;
     s->trailer_done = false;
     s->have_dict = false; s->dictid = 0;
+    s->prime_bits = 0; s->prime_val = 0;
     return Z_OK;
 }
 
@@ -341,7 +344,7 @@ int deflatePending(z_streamp strm, unsigned *pending, int *bits) {
     DState *s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
     if (pending != Z_NULL) *pending = (unsigned)(s->out.size() - s->out_pos);
-    if (bits != Z_NULL) *bits = 0;     // output is handed over in whole bytes
+    if (bits != Z_NULL) *bits = (int)s->prime_bits;     // compressed data ends every call on a byte boundary; only deflatePrime leaves bits
     return Z_OK;
 }
 
@@ -374,9 +377,16 @@ int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, 
     s->tuned = true;
     return Z_OK;
 }
-int deflatePrime(z_streamp strm, int, int) {
-    if (strm) strm->msg = "deflatePrime is not supported by the GPU engine";
-    return Z_STREAM_ERROR;
+int deflatePrime(z_streamp strm, int bits, int value) {     // deflate.c:464-487
+    DState *s = dstate(strm);
+    if (!s || bits < 0 || bits > 32) return Z_STREAM_ERROR;
+    // whole bytes go to the pending output at once (_tr_flush_bits, trees.c:882-886), the rest
+    // waits for the next block
+    uint64_t hold = (uint64_t)s->prime_val | ((uint64_t)((uint32_t)value & (bits == 32 ? 0xffffffffu : ((1u << bits) - 1u))) << s->prime_bits);
+    uint32_t have = s->prime_bits + (uint32_t)bits;
+    while (have >= 8) { s->out.push_back((uint8_t)hold); hold >>= 8; have -= 8; }
+    s->prime_bits = have; s->prime_val = (uint32_t)hold;
+    return Z_OK;
 }
 
 int deflateParams(z_streamp strm, int level, int strategy) {
@@ -528,6 +538,7 @@ struct IState {
     uint32_t check; uint64_t total; // running check value and length of the inflated data
     uint32_t dictid;
     uint64_t out_batch;
+    uint64_t prime_hold; unsigned prime_bits;   // inflatePrime bits waiting in front of the first input byte
 };
 
 inline IState *istate(z_streamp strm) {
@@ -768,6 +779,7 @@ int istate_reset(z_streamp strm, IState *s, bool keep_window) {
     s->head = Z_NULL;
     s->hdr.clear(); s->in.clear(); s->cands.clear(); s->out.clear();
     s->bit_off = 0; s->scanned = 0; s->tried = 0; s->out_pos = 0; s->check = 0; s->dictid = 0;
+    s->prime_hold = 0; s->prime_bits = 0;
     if (!keep_window) s->hist.clear();
     return Z_OK;
 }
@@ -884,6 +896,13 @@ int inflate(z_streamp strm, int flush) {
             continue;
         }
         if (s->mode == IM_BODY) {
+            if (s->prime_bits) {
+                // primed bits become the top bits of the bytes in front of the input
+                const unsigned nb = (s->prime_bits + 7) >> 3, off = nb * 8 - s->prime_bits;
+                const uint64_t v = s->prime_hold << off;
+                for (unsigned i = 0; i < nb; i++) s->in.push_back((uint8_t)(v >> (8 * i)));
+                s->bit_off = off; s->prime_bits = 0; s->prime_hold = 0;
+            }
             const size_t before = s->in.size();
             uint64_t room = (512ull << 20) > before ? (512ull << 20) - before : 0;
             uint64_t take = strm->avail_in < room ? strm->avail_in : room;
@@ -976,10 +995,20 @@ int inflateCopy(z_streamp dest, z_streamp source) {
     return Z_OK;
 }
 
-int inflatePrime(z_streamp strm, int, int) {
-    if (!istate(strm)) return Z_STREAM_ERROR;
-    strm->msg = "inflatePrime is not supported by the GPU engine";
-    return Z_STREAM_ERROR;
+int inflatePrime(z_streamp strm, int bits, int value) {     // inflate.c:230-250
+    IState *s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (bits < 0) { s->prime_hold = 0; s->prime_bits = 0; return Z_OK; }
+    if (bits > 16 || s->prime_bits + (unsigned)bits > 32) return Z_STREAM_ERROR;
+    // Bits can be put in front of deflate data only, and only while no input is buffered
+    // (the reference's bit accumulator is a few bits; here whole batches wait).
+    if (s->mode != IM_BODY || !s->in.empty()) {
+        strm->msg = "inflatePrime is supported on deflate data before its first input only";
+        return Z_STREAM_ERROR;
+    }
+    s->prime_hold += (uint64_t)((unsigned)value & ((1u << bits) - 1u)) << s->prime_bits;
+    s->prime_bits += (unsigned)bits;
+    return Z_OK;
 }
 
 int inflateUndermine(z_streamp strm, int) {      // inflate.c:1485-1500 without INFLATE_ALLOW_INVALID_DISTANCE_TOOFAR_ARRR
