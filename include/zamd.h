@@ -80,7 +80,9 @@ int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_
 /* deflateTune (deflate.c:531-547) for the following deflate calls of this engine:
  * good_length, max_lazy (max_insert_length at levels 1-3), nice_length, max_chain
  * instead of the level's table values; all four 0 = back to the table.  max_chain
- * must be >= 1, and <= 64 at levels 1-3. */
+ * must be >= 1, and <= 64 at levels 1-3.  Values the precomputed-record matcher cannot
+ * express (nice_length < max_lazy, max_chain < 4) switch levels 4-9 to the slower
+ * matcher that follows the parse; the output stays the reference's. */
 int zamd_engine_tune(zamd_engine *e, int good_length, int max_lazy, int nice_length, int max_chain);
 
 /* deflatePrime (deflate.c:464-487) for the next deflate call of this engine only: `bits`

@@ -54,6 +54,8 @@ struct HostFast {
     }
 };
 
+static const int *g_tune;     /* deflateTune values or NULL */
+static int g_tuned_wild;      /* tuned values outside what the record-based matcher reproduces */
 static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t chunk_size, int level, int strategy, int mem_level,
                                          std::vector<uint64_t> &chunk_off)
 {
@@ -62,6 +64,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
     ZcParams P; memset(&P, 0, sizeof P);
     P.level = level; P.strategy = strategy; P.mem_level = mem_level;
     P.good = cfg[level][0]; P.lazy = cfg[level][1]; P.nice = cfg[level][2]; P.chain = cfg[level][3];
+    if (g_tune && level) { P.good = g_tune[0]; P.lazy = g_tune[1]; P.nice = g_tune[2]; P.chain = g_tune[3]; }
     P.hash_bits = mem_level + 7; P.hash_mask = (1u << P.hash_bits) - 1; P.hash_shift = (P.hash_bits + 2) / 3;
     P.lit_bufsize = 1u << (mem_level + 6);
     P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level == 0 ? ZC_PARSE_STORED : level < 4 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
@@ -113,10 +116,27 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
         else {
             /* k_resolve: hop word per position, literal skips to the next match inside a 1024-position tile */
             std::vector<uint32_t> hop(g.len + 1, 0);
+            if (g_hops == 2) {
+                /* k_spec: hops are computed only where a parse arrives; parses start at every 16th position and
+                 * run until they meet a position somebody has been to (0 = nobody) */
+                for (uint32_t s0 = 0; s0 < g.len; s0 += 16)
+                    for (uint32_t i = s0; i < g.len && hop[i] == 0;) {
+                        uint32_t h = zc_hop_direct(win, pd, g.dict_len + i, E, g.corner, P);
+                        if (!h) h = 1;
+                        hop[i] = h;
+                        i += (h & ZC_HOP_MATCH) ? zc_hop_k(h) + zc_hop_len(h) : 1u;
+                    }
+                /* every hop equals what the record-based resolver says */
+                for (uint32_t i = 0; i < g.len; i++) if (hop[i]) {
+                    uint32_t w = zc_resolve_pos(rec, g.dict_len + i, E, P);
+                    if ((w ? w : 1u) != hop[i] && !g_tuned_wild) { fprintf(stderr, "hop mismatch at %u: direct %08x records %08x\n", i, hop[i], w); exit(4); }
+                }
+            } else {
             for (uint32_t i = 0; i < g.len; i++) hop[i] = zc_resolve_pos(rec, g.dict_len + i, E, P);
             for (uint32_t t = 0; t < g.len; t += 1024) {
                 uint32_t te = t + 1024 < g.len ? t + 1024 : g.len, next = te;
                 for (uint32_t i = te; i-- > t;) { if (hop[i] & ZC_HOP_MATCH) next = i; else hop[i] = next - i; }
+            }
             }
             /* k_hop: the serial walk */
             std::vector<uint32_t> arr;
@@ -245,6 +265,12 @@ int main(int argc, char **argv)
         if (kind < 5) zo_corpus_fill(in.data(), n, kind, rnd() | 1);
         else if (kind == 5) for (uint64_t i = 0; i < n; i++) in[i] = (uint8_t)('a' + rnd() % (1 + (it % 16)));
         else { uint32_t per = 1 + rnd() % 300; for (uint64_t i = 0; i < n; i++) in[i] = (uint8_t)(i < per ? rnd() : in[i - per]); for (uint64_t i = 0; i < n / 211; i++) in[rnd() % n] ^= 4; }
+        int tune[4]; g_tune = NULL; g_tuned_wild = 0;
+        if (g_hops == 2 && level >= 4 && rnd() % 3 == 0) {
+            static const int lazies[] = {0, 1, 2, 3, 4, 5, 8, 16, 64, 258, 300}, nices[] = {3, 4, 8, 9, 32, 100, 258, 259, 1000}, chains[] = {1, 2, 3, 5, 8, 17, 40, 64, 100, 500};
+            tune[0] = 1 + (int)(rnd() % 40); tune[1] = lazies[rnd() % 11]; tune[2] = nices[rnd() % 9]; tune[3] = chains[rnd() % 10];
+            g_tune = tune; g_tuned_wild = tune[2] < tune[1] || tune[3] < 4;
+        }
         std::vector<uint64_t> off;
         std::vector<uint8_t> got = emul_chunked(in.data(), n, cs, level, strategy, mem, off);
         std::vector<uint8_t> want(n + n / 4 + 65536);
@@ -254,7 +280,7 @@ int main(int argc, char **argv)
             size_t o = 0, offi = 0, c = 0;
             do {
                 size_t len = n - offi < cs ? n - offi : cs, dict = offi < 32768 ? offi : 32768;
-                size_t r = zo_deflate_chunk(in.data() + offi - dict, dict, len, level, strategy, mem, 15, offi + len >= n, want.data() + o, want.size() - o, NULL);
+                size_t r = zo_deflate_chunk_tuned(in.data() + offi - dict, dict, len, level, strategy, mem, 15, offi + len >= n, g_tune, want.data() + o, want.size() - o, NULL);
                 if (r == (size_t)-1) { printf("oracle failed\n"); return 1; }
                 clen[c++] = (uint32_t)r; o += r; offi += len;
             } while (offi < n);
@@ -264,7 +290,9 @@ int main(int argc, char **argv)
         if (!ok) {
             bad++;
             size_t d = 0; while (d < wl && d < got.size() && got[d] == want[d]) d++;
-            printf("MISMATCH it=%ld n=%llu cs=%u L=%d S=%d M=%d kind=%d got=%zu want=%zu first diff %zu\n", it, (unsigned long long)n, cs, level, strategy, mem, kind, got.size(), wl, d);
+            printf("MISMATCH it=%ld n=%llu cs=%u L=%d S=%d M=%d kind=%d got=%zu want=%zu first diff %zu", it, (unsigned long long)n, cs, level, strategy, mem, kind, got.size(), wl, d);
+            if (g_tune) printf(" tune=%d,%d,%d,%d", g_tune[0], g_tune[1], g_tune[2], g_tune[3]);
+            printf("\n");
             if (bad > 5) break;
         }
     }

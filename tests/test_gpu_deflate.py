@@ -219,3 +219,39 @@ def test_primed_bits_shift_the_first_chunk_only(engine, level, kind, bits):
     assert out == want
     again, _ = engine.deflate_chunks(data, level=level, chunk_size=chunk)      # one call only
     assert again == O.deflate_chunked(data, chunk, level, 0, 8)[0]
+
+
+def test_parse_driven_matcher_is_exact_too():
+    """The matcher that follows the parse (k_spec) instead of searching every position: same bytes, also for
+    deflateTune values only it can express (nice_length below max_lazy, a quarter budget of zero)."""
+    import zlib_amd
+    data = O.corpus(3 * 65536 + 77, 4, 81) + O.corpus(150000, 0, 82) + bytes(70000) + O.corpus(100000, 3, 83)
+    chunk = 131072
+    os.environ["ZAMD_MATCH_SPEC"] = "1"
+    try:
+        eng = zlib_amd.Engine(0)
+    finally:
+        del os.environ["ZAMD_MATCH_SPEC"]
+    for level, strategy in ((4, 0), (6, 0), (6, 1), (6, 4), (9, 0)):
+        out, _ = eng.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk)
+        assert out == O.deflate_chunked(data, chunk, level, strategy, 8)[0], (level, strategy)
+    eng.close()
+
+
+@pytest.mark.parametrize("level,tune", [(6, (4, 64, 8, 128)), (5, (20, 258, 9, 3)), (8, (1, 16, 4, 2)), (6, (33, 1, 8, 2)), (6, (14, 2, 9, 1))])
+def test_tuned_parameters_outside_the_tables_shape(engine, level, tune):
+    """nice_length below max_lazy, chain budgets whose quarter is zero, lazy limits below 3."""
+    data = O.corpus(2 * 65536 + 1234, 0, 85) + O.corpus(60000, 3, 86)
+    chunk = 65536
+    engine.tune(*tune)
+    try:
+        out, offs = engine.deflate_chunks(data, level=level, chunk_size=chunk)
+    finally:
+        engine.tune()
+    want = b""
+    nch = (len(data) + chunk - 1) // chunk
+    for c in range(nch):
+        start = c * chunk
+        dl, ln = min(start, 32768), min(chunk, len(data) - start)
+        want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, level, 0, 8, c == nch - 1, tune=tune)
+    assert out == want

@@ -433,7 +433,7 @@ template <class Rec>
 ZC_HD uint32_t zc_resolve_pos(Rec rec, uint32_t p, uint32_t E, const ZcParams &P)
 {
     uint32_t rf, rq, L, D;
-    if (E - p < ZC_MIN_MATCH) return 0;
+    if (E - p < ZC_MIN_MATCH || P.lazy < ZC_MIN_MATCH) return 0;      /* prev_length (2) < max_lazy_match, deflate.c:1765 */
     rec(p, &rf, &rq);
     if (!zc_accept(rf, rq, ZC_MIN_MATCH - 1, P, &L, &D)) return 0;
     uint32_t k = 0;
@@ -442,6 +442,46 @@ ZC_HD uint32_t zc_resolve_pos(Rec rec, uint32_t p, uint32_t E, const ZcParams &P
         if (L >= P.lazy || E - q < ZC_MIN_MATCH) break;
         rec(q, &rf, &rq);
         if (!zc_accept(rf, rq, L, P, &L2, &D2)) break;
+        L = L2; D = D2; k++;
+    }
+    return zc_hop_pack(k, L, D);
+}
+
+/* The same hop computed from the data instead of from precomputed records: the
+ * searches deflate_slow itself makes when it arrives at p with nothing pending.
+ * zc_walk_direct is longest_match as the parser calls it (deflate.c:1148-1289):
+ * best_len starts at prev_length, the chain budget is quartered from good_match on
+ * (a budget of zero wraps in the reference's do-while and is as good as unbounded).
+ * Only the positions the parser examines are searched. */
+template <class Win, class Pd>
+ZC_HD bool zc_walk_direct(const Win &win, const Pd &pd, uint32_t q, uint32_t E, uint32_t corner, const ZcParams &P,
+                          uint32_t plen, uint32_t *len, uint32_t *dist)
+{
+    ZcMatchState s;
+    if (!zc_match_init(win, pd, q, E, corner, P.nice, s)) return false;
+    if (plen >= s.cap) return false;                       /* nothing can be longer than prev_length */
+    if (plen > ZC_MIN_MATCH - 1) { s.best = plen; s.scan3 = win.load4(q + plen - 2u) & 0x00ffffffu; }
+    uint32_t budget = plen >= P.good ? P.chain >> 2 : P.chain;
+    if (budget == 0) budget = 0x7fffffffu;
+    while (!zc_match_step(win, pd, budget, s)) {}
+    if (s.best <= plen) return false;
+    *len = s.best; *dist = s.bdist;
+    return true;
+}
+ZC_HD bool zc_filtered_out(uint32_t l, uint32_t d, const ZcParams &P)    /* deflate.c:1776-1785 */
+{
+    return l <= 5 && (P.strategy == ZC_STRAT_FILTERED || (l == ZC_MIN_MATCH && d > ZC_TOO_FAR));
+}
+template <class Win, class Pd>
+ZC_HD uint32_t zc_hop_direct(const Win &win, const Pd &pd, uint32_t p, uint32_t E, uint32_t corner, const ZcParams &P)
+{
+    uint32_t L, D, L2, D2, k = 0;
+    if (P.lazy < ZC_MIN_MATCH) return 0;                   /* prev_length (2) < max_lazy_match, deflate.c:1765 */
+    if (!zc_walk_direct(win, pd, p, E, corner, P, ZC_MIN_MATCH - 1, &L, &D) || zc_filtered_out(L, D, P)) return 0;
+    for (;;) {
+        uint32_t q = p + k + 1;
+        if (L >= P.lazy || E - q < ZC_MIN_MATCH) break;
+        if (!zc_walk_direct(win, pd, q, E, corner, P, L, &L2, &D2) || zc_filtered_out(L2, D2, P)) break;
         L = L2; D = D2; k++;
     }
     return zc_hop_pack(k, L, D);

@@ -345,6 +345,8 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     }
 }
 
+#include "zamd_spec_impl.h"
+
 /* ------------------------------------------------------------------ k_parse
  * One wavefront per chunk.  The lazy-evaluation state machine is serial, so all
  * 64 lanes run it redundantly (every value is wave-uniform, branches are scalar)
@@ -451,8 +453,11 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
     const uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;
+    uint32_t *hopw = J.hop + (uint64_t)lc * J.P.chunk_size;
     uint32_t *arr = J.arr + (uint64_t)lc * (J.P.chunk_size / 2);
-    uint32_t i = 0, H = 0, base = 0xffff0000u;
+    GlbWin gwin; gwin.b = J.in + g.dstart; gwin.n = J.n - g.dstart;
+    GlbPd gpd; gpd.pd = J.pdist + (g.dstart - J.pdist_base); gpd.len = J.pdist_len - (g.dstart - J.pdist_base);
+    uint32_t i = 0, H = 0, base = 0xffff0000u, nfall = 0;
     while (i < g.len) {
         if (i - base >= ZK_HOP_TILE) {
             base = i & ~(ZK_HOP_TILE - 1u);
@@ -467,13 +472,27 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
             __syncthreads();
         }
         uint32_t h = s_tile[i - base];
+        const bool fell = h == 0;
+        if (fell) {
+            /* nobody has been here (k_spec): search as the parser would, from global memory; every lane the same */
+            h = zc_hop_direct(gwin, gpd, g.dict_len + i, g.dict_len + g.len, g.corner, J.P);
+            if (!h) h = 1;
+            nfall++;
+        }
         if (h & ZC_HOP_MATCH) {
             if (lane == 0) arr[H] = i;
+            if (lane == 0 && fell) hopw[i] = h;      /* k_expand reads the hop word */
             H++;
             i += zc_hop_k(h) + zc_hop_len(h);
-        } else i += h;
+        } else if (h != 1) i += h;
+        else {
+            /* a run of single literals: every "1" that follows a "1" is on the parse as well */
+            uint32_t j = i - base + 1u + lane;
+            unsigned long long m = __ballot(j >= ZK_HOP_TILE || s_tile[j] != 1u);
+            i += 1u + (m ? (uint32_t)__ffsll((long long)m) - 1u : 64u);
+        }
     }
-    if (lane == 0) J.nhop[lc] = H;
+    if (lane == 0) { J.nhop[lc] = H; if (nfall) atomicAdd(J.err + 1, nfall); }
 }
 
 #define ZK_EXPAND_THREADS 256
@@ -869,10 +888,11 @@ struct zamd_engine {
     hipEvent_t ev_scan[ZE_STREAMS], ev_init;
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
+    int spec_match;                 /* follow the parse (k_spec) instead of searching every position (k_match) */
     uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
     int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
     uint64_t ws_budget;
-    uint64_t *d_total; uint32_t *d_err;
+    uint64_t *d_total; uint32_t *d_err; uint32_t last_fallback_hops;
     uint64_t *d_off_own; uint64_t d_off_cap;
     /* timing */
     hipEvent_t ev_call[2];
@@ -934,6 +954,7 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     memset((void *)e, 0, sizeof *e);
     for (int i = 0; i < ZE_STREAMS; i++) e->ws[i] = ZeWorkspace();
     e->nstreams = 4;                 /* one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4) */
+    e->spec_match = getenv("ZAMD_MATCH_SPEC") ? 1 : 0;
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->device = device;
     e->ws_budget = workspace_bytes ? workspace_bytes : (48ull << 30);
@@ -944,7 +965,7 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     HIPCHK(hipEventCreateWithFlags(&e->ev_init, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&e->ev_call[i]));
     HIPCHK(hipMalloc((void **)&e->d_total, 8));
-    HIPCHK(hipMalloc((void **)&e->d_err, 4));
+    HIPCHK(hipMalloc((void **)&e->d_err, 16));       /* [0] error flags, [1] hops k_hop had to search itself */
     crc_host_init();
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_crc), &h_crc, sizeof h_crc));
     e->cap_tm = 512; e->tm = (zamd_engine::Tm *)calloc((size_t)e->cap_tm, sizeof(zamd_engine::Tm));
@@ -1077,7 +1098,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     hipStream_t s0 = e->st[0];
     HIPCHK(hipEventRecord(e->ev_call[0], s0));
     HIPCHK(hipMemsetAsync(e->d_total, 0, 8, s0));
-    HIPCHK(hipMemsetAsync(e->d_err, 0, 4, s0));
+    HIPCHK(hipMemsetAsync(e->d_err, 0, 16, s0));
     HIPCHK(hipMemsetAsync(d_out, 0, out_cap, s0));
     HIPCHK(hipEventRecord(e->ev_init, s0));
     HIPCHK(hipEventRecord(e->ev_scan[NS - 1], s0));     /* batch 0's predecessor "scan" */
@@ -1104,7 +1125,20 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(ZK_CHAIN_THREADS), 0, s, J);
             tm_end(e, s, slot);
         }
-        if (P.parser == ZC_PARSE_SLOW || P.parser == ZC_PARSE_RLE) {
+        /* k_match's records reproduce neither a nice length below the lazy limit nor a quarter budget of zero
+         * (which wraps in the reference): those searches follow the parse (k_spec) */
+        const bool dense = P.parser == ZC_PARSE_RLE || !(e->spec_match || P.nice < P.lazy || P.chain < 4);
+        if (P.parser == ZC_PARSE_SLOW && !dense) {
+            tm_begin(e, s, 1, &slot);
+            HIPCHK(hipMemsetAsync(w.hop, 0, (uint64_t)J.nchunks * chunk_size * 4u, s));
+            static int sv = getenv("ZAMD_SV") ? atoi(getenv("ZAMD_SV")) : 0;
+            dim3 grid(J.nchunks * tiles), blk(ZK_MATCH_THREADS);
+            if (sv == 1) hipLaunchKernelGGL((k_spec<16>), grid, blk, 0, s, J, tiles);
+            else if (sv == 2) hipLaunchKernelGGL((k_spec<44>), grid, blk, 0, s, J, tiles);
+            else hipLaunchKernelGGL((k_spec<32>), grid, blk, 0, s, J, tiles);
+            tm_end(e, s, slot);
+        }
+        if (dense) {
             tm_begin(e, s, 1, &slot);
             {
                 static int mv = getenv("ZAMD_MV") ? atoi(getenv("ZAMD_MV")) : 0;
@@ -1128,9 +1162,9 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             HIPCHK(hipMemsetAsync(w.fhead, 0, (uint64_t)J.nchunks * ZF_ROW * 2u, s));
             hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
-        else if (P.parser == ZC_PARSE_SLOW && !getenv("ZAMD_SERIAL_PARSE")) {
+        else if (P.parser == ZC_PARSE_SLOW && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {
             const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
-            hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
+            if (dense) hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
             hipLaunchKernelGGL(k_hop, dim3(J.nchunks), dim3(64), 0, s, J);
             hipLaunchKernelGGL(k_expand, dim3(J.nchunks), dim3(ZK_EXPAND_THREADS), 0, s, J);
         } else hipLaunchKernelGGL(k_parse, dim3(J.nchunks), dim3(64), 0, s, J);
@@ -1157,6 +1191,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     uint64_t total = 0; uint32_t err = 0;
     HIPCHK(hipMemcpy(&total, e->d_total, 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&err, e->d_err, 4, hipMemcpyDeviceToHost));
+    { uint32_t nf = 0; HIPCHK(hipMemcpy(&nf, e->d_err + 1, 4, hipMemcpyDeviceToHost)); e->last_fallback_hops = nf; }
     for (int k = 0; k < 12; k++) { e->t_ms[k] = 0; e->t_n[k] = 0; }
     for (int i = 0; i < e->n_tm; i++) { float ms = 0; if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->t_ms[e->tm[i].which] += ms; e->t_n[e->tm[i].which]++; } }
     { float ms = 0; if (hipEventElapsedTime(&ms, e->ev_call[0], e->ev_call[1]) == hipSuccess) { e->t_ms[6] = ms; e->t_n[6] = 1; } }
@@ -1176,6 +1211,7 @@ extern "C" int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, ui
 extern "C" double zamd_last_timing_ms(zamd_engine *e, int which, int *launches)
 {
     if (!e || which < 0 || which > 11) return 0;
+    if (which == 9) { if (launches) *launches = 0; return (double)e->last_fallback_hops; }   /* a count, not a time */
     if (launches) *launches = e->t_n[which];
     return e->t_ms[which];
 }
