@@ -4,13 +4,16 @@ ARCH ?= gfx950
 SRCS = zlib_amd/csrc/zamd_engine.hip zlib_amd/csrc/zamd_corpus.cpp
 HDRS = zlib_amd/csrc/zamd_core.h zlib_amd/csrc/zamd_inflate_impl.h zlib_amd/csrc/zamd_fast_impl.h zlib_amd/csrc/zamd_spec_impl.h include/zamd.h
 
-all: zlib_amd/libzamd.so zlib_amd/libzamd_z.so oracle
+all: zlib_amd/libzamd.so zlib_amd/libzamd_z.so examples/zamd_gzip oracle
 
 zlib_amd/libzamd.so: $(SRCS) $(HDRS)
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -o $@ $(SRCS)
 
-zlib_amd/libzamd_z.so: zlib_amd/csrc/zamd_zlib.cpp include/zamd_zlib.h include/zamd.h zlib_amd/libzamd.so
-	g++ -O2 -std=c++17 -fPIC -shared -pthread -o $@ zlib_amd/csrc/zamd_zlib.cpp -Lzlib_amd -lzamd -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN'
+zlib_amd/libzamd_z.so: zlib_amd/csrc/zamd_zlib.cpp zlib_amd/csrc/zamd_gz.cpp include/zamd_zlib.h include/zamd.h zlib_amd/libzamd.so
+	g++ -O2 -std=c++17 -fPIC -shared -pthread -o $@ zlib_amd/csrc/zamd_zlib.cpp zlib_amd/csrc/zamd_gz.cpp -Lzlib_amd -lzamd -Wl,-Bsymbolic -Wl,-rpath,'$$ORIGIN'
+
+examples/zamd_gzip: examples/zamd_gzip.c include/zamd_zlib.h zlib_amd/libzamd_z.so
+	gcc -O2 -Iinclude -o $@ examples/zamd_gzip.c -Lzlib_amd -lzamd_z -lzamd -Wl,-rpath,'$$ORIGIN/../zlib_amd'
 
 oracle:
 	$(MAKE) -C oracle

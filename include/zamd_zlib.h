@@ -153,6 +153,45 @@ uLong crc32_combine(uLong crc1, uLong crc2, z_off_t len2);
 uLong crc32_combine64(uLong crc1, uLong crc2, z_off64_t len2);
 const z_crc_t *get_crc_table(void);
 
+/* gz* file layer: gzlib.c, gzread.c, gzwrite.c, gzclose.c (declarations zlib.h:1224-1552, 1670-1728).
+ * Same behaviour and return values; the buffers default to 32 MiB (gzbuffer() or the
+ * environment variable ZAMD_GZ_BUF_MIB change that) because every call into the
+ * codec that makes progress is a GPU round trip. */
+#include <stdarg.h>
+typedef struct gzFile_s *gzFile;
+struct gzFile_s { unsigned have; unsigned char *next; z_off64_t pos; };                             /* zlib.h:1670-1674 */
+gzFile gzopen(const char *path, const char *mode);                                                  /* gzlib.c:268 */
+gzFile gzopen64(const char *path, const char *mode);                                                /* gzlib.c:276 */
+gzFile gzdopen(int fd, const char *mode);                                                           /* gzlib.c:284 */
+int gzbuffer(gzFile file, unsigned size);                                                           /* gzlib.c:314 */
+int gzsetparams(gzFile file, int level, int strategy);                                              /* gzwrite.c:513 */
+int gzread(gzFile file, voidp buf, unsigned len);                                                   /* gzread.c:288 */
+int gzwrite(gzFile file, const void *buf, unsigned len);                                            /* gzwrite.c:165 */
+int gzprintf(gzFile file, const char *format, ...);                                                 /* gzwrite.c:375 */
+int gzvprintf(gzFile file, const char *format, va_list va);                                         /* gzwrite.c:311 */
+int gzputs(gzFile file, const char *s);                                                             /* gzwrite.c:294 */
+char *gzgets(gzFile file, char *buf, int len);                                                      /* gzread.c:483 */
+int gzputc(gzFile file, int c);                                                                     /* gzwrite.c:246 */
+int gzgetc(gzFile file);                                                                            /* gzread.c:387 */
+int gzgetc_(gzFile file);                                                                           /* gzread.c:416 */
+int gzungetc(int c, gzFile file);                                                                   /* gzread.c:423 */
+int gzflush(gzFile file, int flush);                                                                /* gzwrite.c:478 */
+z_off_t gzseek(gzFile file, z_off_t offset, int whence);                                            /* gzlib.c:439 */
+z_off64_t gzseek64(gzFile file, z_off64_t offset, int whence);                                      /* gzlib.c:362 */
+int gzrewind(gzFile file);                                                                          /* gzlib.c:339 */
+z_off_t gztell(gzFile file);                                                                        /* gzlib.c:468 */
+z_off64_t gztell64(gzFile file);                                                                    /* gzlib.c:451 */
+z_off_t gzoffset(gzFile file);                                                                      /* gzlib.c:501 */
+z_off64_t gzoffset64(gzFile file);                                                                  /* gzlib.c:478 */
+int gzeof(gzFile file);                                                                             /* gzlib.c:511 */
+int gzdirect(gzFile file);                                                                          /* gzread.c:547 */
+int gzclose(gzFile file);                                                                           /* gzclose.c:11 */
+int gzclose_r(gzFile file);                                                                         /* gzread.c:567 */
+int gzclose_w(gzFile file);                                                                         /* gzwrite.c:555 */
+const char *gzerror(gzFile file, int *errnum);                                                      /* gzlib.c:528 */
+void gzclearerr(gzFile file);                                                                       /* gzlib.c:549 */
+#define gzgetc(g) ((g)->have ? ((g)->have--, (g)->pos++, *((g)->next)++) : gzgetc(g))               /* zlib.h:1684-1686 */
+
 #define deflateInit(strm, level) deflateInit_((strm), (level), ZLIB_VERSION, (int)sizeof(z_stream))
 #define deflateInit2(strm, level, method, windowBits, memLevel, strategy) \
     deflateInit2_((strm), (level), (method), (windowBits), (memLevel), (strategy), ZLIB_VERSION, (int)sizeof(z_stream))

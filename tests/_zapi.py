@@ -72,6 +72,32 @@ def lib():
         for name in ("adler32_combine", "crc32_combine", "adler32_combine64", "crc32_combine64"):
             getattr(l, name).argtypes = [C.c_ulong, C.c_ulong, C.c_long]; getattr(l, name).restype = C.c_ulong
         l.get_crc_table.restype = C.POINTER(C.c_uint)
+        # gz* file layer (zlib.h:1224-1552)
+        G = C.c_void_p
+        for name in ("gzopen", "gzopen64"):
+            getattr(l, name).argtypes = [C.c_char_p, C.c_char_p]; getattr(l, name).restype = G
+        l.gzdopen.argtypes = [C.c_int, C.c_char_p]; l.gzdopen.restype = G
+        l.gzbuffer.argtypes = [G, C.c_uint]
+        l.gzsetparams.argtypes = [G, C.c_int, C.c_int]
+        l.gzread.argtypes = [G, C.c_void_p, C.c_uint]
+        l.gzwrite.argtypes = [G, C.c_char_p, C.c_uint]
+        l.gzputs.argtypes = [G, C.c_char_p]
+        l.gzgets.argtypes = [G, C.c_void_p, C.c_int]; l.gzgets.restype = C.c_void_p
+        l.gzputc.argtypes = [G, C.c_int]
+        l.gzgetc.argtypes = [G]; l.gzgetc_.argtypes = [G]
+        l.gzungetc.argtypes = [C.c_int, G]
+        l.gzflush.argtypes = [G, C.c_int]
+        l.gzseek.argtypes = [G, C.c_long, C.c_int]; l.gzseek.restype = C.c_long
+        l.gzseek64.argtypes = [G, C.c_longlong, C.c_int]; l.gzseek64.restype = C.c_longlong
+        for name in ("gztell", "gzoffset"):
+            getattr(l, name).argtypes = [G]; getattr(l, name).restype = C.c_long
+        for name in ("gztell64", "gzoffset64"):
+            getattr(l, name).argtypes = [G]; getattr(l, name).restype = C.c_longlong
+        for name in ("gzrewind", "gzeof", "gzdirect", "gzclose", "gzclose_r", "gzclose_w"):
+            getattr(l, name).argtypes = [G]
+        l.gzerror.argtypes = [G, C.POINTER(C.c_int)]; l.gzerror.restype = C.c_char_p
+        l.gzclearerr.argtypes = [G]; l.gzclearerr.restype = None
+        l.gzprintf.restype = C.c_int
         _lib = l
     return _lib
 

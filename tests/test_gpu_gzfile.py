@@ -1,0 +1,211 @@
+"""GPU tests: the gz* file layer of libzamd_z.so (gzlib.c, gzread.c, gzwrite.c of the reference) — files it
+writes are read by Python's gzip module (system zlib), files Python writes are read by it, and the calls of
+the reference's own test (test/example.c:88-170, test_gzio) give the reference's results."""
+import ctypes as C
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import _oracle as O
+import _zapi as Z
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _read_all(l, g, piece):
+    buf = C.create_string_buffer(piece)
+    out = bytearray()
+    while True:
+        n = l.gzread(g, buf, piece)
+        assert n >= 0, l.gzerror(g, None)
+        if n == 0:
+            break
+        out += buf.raw[:n]
+    return bytes(out)
+
+
+def test_the_calls_of_the_reference_test(tmp_path):
+    """test/example.c:88-170: putc, puts, printf, a seek while writing, then read, seek back, getc, ungetc, gets."""
+    l = Z.lib()
+    name = str(tmp_path / "foo.gz").encode()
+    g = l.gzopen(name, b"wb")
+    assert g
+    assert l.gzputc(g, ord("h")) == ord("h")
+    assert l.gzputs(g, b"ello") == 4
+    assert l.gzprintf(C.c_void_p(g), b", %s!", b"hello") == 8
+    assert l.gzseek(g, 1, 1) == 14                      # one zero byte more
+    assert l.gztell(g) == 14
+    assert l.gzclose(g) == Z.Z_OK
+    assert gzip.open(name.decode()).read() == b"hello, hello!\0"
+
+    g = l.gzopen(name, b"rb")
+    assert g
+    buf = C.create_string_buffer(64)
+    assert l.gzread(g, buf, 64) == 14
+    assert buf.raw[:14] == b"hello, hello!\0"
+    assert l.gzseek(g, -8, 1) == 6
+    assert l.gztell(g) == 6
+    assert l.gzgetc(g) == ord(" ")
+    assert l.gzungetc(ord(" "), g) == ord(" ")
+    line = C.create_string_buffer(64)
+    assert l.gzgets(g, line, 64) == C.addressof(line)
+    assert line.value == b" hello!"
+    assert line.raw[:9] == b" hello!\0\0"                # the zero byte of the seek, then the terminator
+    assert l.gzeof(g) == 1 and l.gzgetc(g) == -1          # gzgets ran into the end looking for a newline
+    assert l.gzdirect(g) == 0
+    assert l.gzclose(g) == Z.Z_OK
+
+
+def test_files_written_here_are_gzip_files(tmp_path):
+    l = Z.lib()
+    data = O.corpus(5 * (1 << 20) + 4321, 4, 101)
+    name = str(tmp_path / "w.gz").encode()
+    g = l.gzopen(name, b"wb6")
+    assert g
+    assert l.gzbuffer(g, 1 << 20) == 0
+    pos = 0
+    for step in (1, 7, 100000, 3 << 20, 12345, 1 << 20):            # small writes are collected, large ones go straight through
+        piece = data[pos:pos + step]
+        assert l.gzwrite(g, piece, len(piece)) == len(piece)
+        pos += len(piece)
+        if step == 100000:
+            assert l.gzflush(g, Z.Z_SYNC_FLUSH) == Z.Z_OK
+        if step == 12345:
+            assert l.gzsetparams(g, 9, 1) == Z.Z_OK
+    rest = data[pos:]
+    assert l.gzwrite(g, rest, len(rest)) == len(rest)
+    assert l.gztell(g) == len(data)
+    assert l.gzbuffer(g, 4096) == -1                               # too late
+    assert l.gzclose(g) == Z.Z_OK
+    assert gzip.open(name.decode()).read() == data
+
+    # append: a second member, and gzip readers see the concatenation
+    g = l.gzopen(name, b"ab1")
+    assert l.gzwrite(g, b"tail", 4) == 4
+    assert l.gzclose(g) == Z.Z_OK
+    assert gzip.open(name.decode()).read() == data + b"tail"
+
+    # and back through this library, in ragged reads
+    g = l.gzopen(name, b"rb")
+    assert l.gzbuffer(g, 1 << 20) == 0
+    assert _read_all(l, g, 777777) == data + b"tail"
+    assert l.gzeof(g) == 1
+    err = C.c_int(99)
+    assert l.gzerror(g, C.byref(err)) == b"" and err.value == Z.Z_OK
+    assert l.gzclose(g) == Z.Z_OK
+
+
+def test_files_written_by_the_system_zlib_are_read(tmp_path):
+    l = Z.lib()
+    lines = b"".join(b"line %d of the file\n" % i for i in range(200000))
+    name = str(tmp_path / "r.gz")
+    with gzip.open(name, "wb", compresslevel=6) as f:
+        f.write(lines)
+    with open(name, "ab") as f:                                     # a second member, then bytes that are no gzip stream
+        f.write(gzip.compress(b"second member\n") + b"trailing garbage")
+    g = l.gzopen(name.encode(), b"r")
+    assert g
+    buf = C.create_string_buffer(256)
+    for i in (0, 1, 2):
+        assert l.gzgets(g, buf, 256) and buf.value == b"line %d of the file\n" % i
+    assert l.gzgets(g, buf, 8) and buf.value == b"line 3 "              # len - 1 bytes at most
+    here = l.gztell(g)
+    assert l.gzseek(g, len(lines) - 5, 0) == len(lines) - 5            # forward: by reading on
+    rest = _read_all(l, g, 4096)
+    assert rest == b"file\n" + b"second member\n"                       # garbage behind the last member is ignored (gzread.c:144-151)
+    assert l.gzseek(g, here, 0) == here                                 # backward: rewind and read again
+    assert l.gzgets(g, buf, 256) and buf.value == b"of the file\n"
+    assert l.gzrewind(g) == 0 and l.gztell(g) == 0
+    assert l.gzread(g, buf, 5) == 5 and buf.raw[:5] == b"line "
+    assert l.gzoffset(g) > 0
+    assert l.gzclose_r(g) == Z.Z_OK
+
+
+def test_transparent_files(tmp_path):
+    l = Z.lib()
+    plain = O.corpus(300000, 0, 103)
+    name = str(tmp_path / "plain.txt")
+    open(name, "wb").write(plain)
+    g = l.gzopen(name.encode(), b"rb")
+    assert l.gzdirect(g) == 1
+    assert _read_all(l, g, 65536) == plain
+    assert l.gzseek(g, 1000, 0) == 1000                               # plain files are sought directly (gzlib.c:394-407)
+    buf = C.create_string_buffer(10)
+    assert l.gzread(g, buf, 10) == 10 and buf.raw == plain[1000:1010]
+    assert l.gzclose(g) == Z.Z_OK
+    # 'T' writes without compressing
+    name2 = str(tmp_path / "t.out")
+    g = l.gzopen(name2.encode(), b"wbT")
+    assert l.gzwrite(g, plain, len(plain)) == len(plain)
+    assert l.gzclose(g) == Z.Z_OK
+    assert open(name2, "rb").read() == plain
+    assert not l.gzopen(name.encode(), b"rT") and not l.gzopen(name.encode(), b"r+") and not l.gzopen(name.encode(), b"q")
+    empty = str(tmp_path / "empty")
+    open(empty, "wb").close()
+    g = l.gzopen(empty.encode(), b"rb")
+    assert l.gzread(g, buf, 10) == 0 and l.gzeof(g) == 1 and l.gzdirect(g) == 1
+    assert l.gzclose(g) == Z.Z_OK
+
+
+def test_damaged_files_report_the_reference_errors(tmp_path):
+    l = Z.lib()
+    data = O.corpus(400000, 0, 105)
+    blob = gzip.compress(data, 6)
+    cut = str(tmp_path / "cut.gz")
+    open(cut, "wb").write(blob[:len(blob) // 2])
+    g = l.gzopen(cut.encode(), b"rb")
+    got = bytearray()
+    buf = C.create_string_buffer(65536)
+    while True:
+        n = l.gzread(g, buf, 65536)
+        if n <= 0:
+            break
+        got += buf.raw[:n]
+    assert data.startswith(bytes(got)) and len(got) > 0
+    err = C.c_int(0)
+    msg = l.gzerror(g, C.byref(err))
+    assert err.value == Z.Z_BUF_ERROR and msg == cut.encode() + b": unexpected end of file"      # gzread.c:186
+    assert l.gzclose(g) == Z.Z_BUF_ERROR                                                        # gzread.c:588
+    bad = bytearray(blob)
+    bad[-6] ^= 0x10                                                                              # inside the stored crc
+    badname = str(tmp_path / "bad.gz")
+    open(badname, "wb").write(bytes(bad))
+    g = l.gzopen(badname.encode(), b"rb")
+    while True:
+        n = l.gzread(g, buf, 65536)
+        if n <= 0:
+            break
+    assert n == -1
+    msg = l.gzerror(g, C.byref(err))
+    assert err.value == Z.Z_DATA_ERROR and msg == badname.encode() + b": incorrect data check"
+    assert l.gzread(g, buf, 10) == -1
+    l.gzclearerr(g)
+    assert l.gzerror(g, C.byref(err)) == b"" and err.value == Z.Z_OK
+    assert l.gzclose(g) == Z.Z_OK
+    # a write handle refuses reads and the other way round
+    g = l.gzopen(str(tmp_path / "x.gz").encode(), b"wb")
+    assert l.gzread(g, buf, 10) == -1 and l.gzgetc(g) == -1 and l.gzclose_r(g) == Z.Z_STREAM_ERROR
+    assert l.gzflush(g, 9) == Z.Z_STREAM_ERROR
+    assert l.gzseek(g, -1, 1) == -1                                                             # no way back while writing
+    assert l.gzclose(g) == Z.Z_OK
+    assert gzip.open(str(tmp_path / "x.gz")).read() == b""
+
+
+def test_the_example_program_on_a_64_mib_file(tmp_path):
+    """The reference's CPU-runnable configuration (minigzip -6 on a 64 MiB mixed file) through examples/zamd_gzip."""
+    import zlib_amd
+    exe = os.path.join(ROOT, "examples", "zamd_gzip")
+    assert os.path.exists(exe), "run make"
+    data = bytes(zlib_amd.corpus(64 << 20, 4, 5, piece_bytes=16 << 20, threads=8))
+    name = str(tmp_path / "mixed.bin")
+    open(name, "wb").write(data)
+    subprocess.run([exe, "-6", name], check=True, timeout=300)
+    packed = open(name + ".gz", "rb").read()
+    assert len(packed) < len(data) * 0.5
+    assert gzip.decompress(packed) == data
+    os.remove(name)
+    subprocess.run([exe, "-d", name + ".gz"], check=True, timeout=300)
+    assert open(name, "rb").read() == data

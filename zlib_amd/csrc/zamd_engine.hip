@@ -446,7 +446,9 @@ __global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t t
     if (tid < tl) J.hop[(uint64_t)lc * J.P.chunk_size + i0 + tid] = h;
 }
 
-#define ZK_HOP_TILE 2048u
+#define ZK_HOP_TILE 512u
+/* SPEC: the hop words come from k_spec: 0 = nobody has been at this position, literals are single steps */
+template <bool SPEC>
 __global__ __launch_bounds__(64) void k_hop(ZkJob J)
 {
     __shared__ uint32_t s_tile[ZK_HOP_TILE];
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
             __syncthreads();
         }
         uint32_t h = s_tile[i - base];
-        const bool fell = h == 0;
+        const bool fell = SPEC && h == 0;
         if (fell) {
             /* nobody has been here (k_spec): search as the parser would, from global memory; every lane the same */
             h = zc_hop_direct(gwin, gpd, g.dict_len + i, g.dict_len + g.len, g.corner, J.P);
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
             if (lane == 0 && fell) hopw[i] = h;      /* k_expand reads the hop word */
             H++;
             i += zc_hop_k(h) + zc_hop_len(h);
-        } else if (h != 1) i += h;
+        } else if (!SPEC || h != 1) i += h;
         else {
             /* a run of single literals: every "1" that follows a "1" is on the parse as well */
             uint32_t j = i - base + 1u + lane;
@@ -1165,7 +1167,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         else if (P.parser == ZC_PARSE_SLOW && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {
             const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
             if (dense) hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
-            hipLaunchKernelGGL(k_hop, dim3(J.nchunks), dim3(64), 0, s, J);
+            if (dense) hipLaunchKernelGGL(k_hop<false>, dim3(J.nchunks), dim3(64), 0, s, J);
+            else hipLaunchKernelGGL(k_hop<true>, dim3(J.nchunks), dim3(64), 0, s, J);
             hipLaunchKernelGGL(k_expand, dim3(J.nchunks), dim3(ZK_EXPAND_THREADS), 0, s, J);
         } else hipLaunchKernelGGL(k_parse, dim3(J.nchunks), dim3(64), 0, s, J);
         tm_end(e, s, slot);

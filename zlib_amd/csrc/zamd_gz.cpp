@@ -1,0 +1,670 @@
+/*
+ * zamd_gz.cpp — the gz* file layer of zlib 1.2.8 (gzlib.c, gzread.c, gzwrite.c,
+ * gzclose.c) on top of the stream API of this library (zamd_zlib.cpp), so that a
+ * program written against gzopen/gzread/gzwrite runs its compression on the GPU.
+ *
+ * Behaviour follows the reference function by function (cited below); what
+ * differs is sizing.  Every deflate()/inflate() call that makes progress is a GPU
+ * round trip, so the buffers default to 32 MiB (the reference: 8 KiB, gzguts.h:147)
+ * — gzbuffer() and ZAMD_GZ_BUF_MIB change that — and reads hand inflate() the whole
+ * input buffer at once.
+ */
+#include "../../include/zamd_zlib.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <limits.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+enum { GZ_NONE = 0, GZ_READ = 7247, GZ_WRITE = 31153, GZ_APPEND = 1 };   /* gzguts.h:150-153 */
+enum { LOOK = 0, COPY = 1, GZIP = 2 };                                    /* gzguts.h:155-157 */
+
+struct GzFile {
+    gzFile_s x;                 /* what the gzgetc() macro of zlib.h reads: must come first (gzguts.h:160-162) */
+    int mode, fd;
+    std::string path;
+    unsigned size, want;        /* buffer size in use (0: nothing allocated yet), requested size */
+    std::vector<unsigned char> in, out;
+    int direct;
+    /* reading */
+    int how;
+    z_off64_t start;
+    int eof, past;
+    /* writing */
+    int level, strategy;
+    /* seek request */
+    z_off64_t skip; int seek;
+    /* error */
+    int err; std::string msg;
+    z_stream strm;
+};
+
+inline GzFile *gz(gzFile f) { return (GzFile *)f; }
+inline bool fatal(const GzFile *s) { return s->err != Z_OK && s->err != Z_BUF_ERROR; }
+
+void set_error(GzFile *s, int err, const char *msg)      /* gz_error, gzlib.c:575-615 */
+{
+    if (err != Z_OK && err != Z_BUF_ERROR) s->x.have = 0;
+    s->err = err;
+    if (msg == NULL) s->msg.clear();
+    else if (err == Z_MEM_ERROR) s->msg = "out of memory";
+    else s->msg = s->path + ": " + msg;
+}
+
+void reset(GzFile *s)                                    /* gz_reset, gzlib.c:75-88 */
+{
+    s->x.have = 0;
+    if (s->mode == GZ_READ) { s->eof = 0; s->past = 0; s->how = LOOK; }
+    s->seek = 0;
+    set_error(s, Z_OK, NULL);
+    s->x.pos = 0;
+    s->strm.avail_in = 0;
+}
+
+unsigned default_want()
+{
+    const char *v = getenv("ZAMD_GZ_BUF_MIB");
+    unsigned long mib = v ? strtoul(v, NULL, 10) : 32;
+    if (mib < 1) mib = 1;
+    if (mib > 1024) mib = 1024;
+    return (unsigned)(mib << 20);
+}
+
+gzFile open_file(const char *path, int fd, const char *mode)      /* gz_open, gzlib.c:91-265 */
+{
+    if (path == NULL) return NULL;
+    GzFile *s = new (std::nothrow) GzFile();
+    if (s == NULL) return NULL;
+    memset(&s->x, 0, sizeof s->x);
+    memset(&s->strm, 0, sizeof s->strm);
+    s->size = 0; s->want = default_want();
+    s->mode = GZ_NONE; s->level = Z_DEFAULT_COMPRESSION; s->strategy = Z_DEFAULT_STRATEGY; s->direct = 0;
+    s->err = Z_OK; s->how = LOOK; s->eof = s->past = 0; s->seek = 0; s->skip = 0; s->start = 0;
+    int cloexec = 0, exclusive = 0;
+    for (; *mode; mode++) {
+        if (*mode >= '0' && *mode <= '9') { s->level = *mode - '0'; continue; }
+        switch (*mode) {
+        case 'r': s->mode = GZ_READ; break;
+        case 'w': s->mode = GZ_WRITE; break;
+        case 'a': s->mode = GZ_APPEND; break;
+        case '+': delete s; return NULL;               /* no reading and writing at once */
+        case 'e': cloexec = 1; break;
+        case 'x': exclusive = 1; break;
+        case 'f': s->strategy = Z_FILTERED; break;
+        case 'h': s->strategy = Z_HUFFMAN_ONLY; break;
+        case 'R': s->strategy = Z_RLE; break;
+        case 'F': s->strategy = Z_FIXED; break;
+        case 'T': s->direct = 1; break;
+        default: break;                                /* 'b' and anything unknown */
+        }
+    }
+    if (s->mode == GZ_NONE) { delete s; return NULL; }
+    if (s->mode == GZ_READ) {
+        if (s->direct) { delete s; return NULL; }      /* transparent reading cannot be forced */
+        s->direct = 1;                                 /* what an empty file is */
+    }
+    s->path = path;
+    int oflag = (cloexec ? O_CLOEXEC : 0) |
+                (s->mode == GZ_READ ? O_RDONLY
+                                    : (O_WRONLY | O_CREAT | (exclusive ? O_EXCL : 0) | (s->mode == GZ_WRITE ? O_TRUNC : O_APPEND)));
+#ifdef O_LARGEFILE
+    oflag |= O_LARGEFILE;
+#endif
+    s->fd = fd > -1 ? fd : open(path, oflag, 0666);
+    if (s->fd == -1) { delete s; return NULL; }
+    if (s->mode == GZ_APPEND) s->mode = GZ_WRITE;
+    if (s->mode == GZ_READ) {
+        s->start = lseek(s->fd, 0, SEEK_CUR);
+        if (s->start == -1) s->start = 0;
+    }
+    reset(s);
+    return (gzFile)s;
+}
+
+/* ------------------------------------------------------------------ reading */
+int load(GzFile *s, unsigned char *buf, unsigned len, unsigned *have)    /* gz_load, gzread.c:20-42 */
+{
+    ssize_t r = 0;
+    *have = 0;
+    while (*have < len) {
+        r = read(s->fd, buf + *have, len - *have);
+        if (r <= 0) break;
+        *have += (unsigned)r;
+    }
+    if (r < 0) { set_error(s, Z_ERRNO, strerror(errno)); return -1; }
+    if (r == 0) s->eof = 1;
+    return 0;
+}
+
+int refill(GzFile *s)                                   /* gz_avail, gzread.c:51-75 */
+{
+    if (fatal(s)) return -1;
+    if (s->eof == 0) {
+        z_stream &z = s->strm;
+        if (z.avail_in) memmove(s->in.data(), z.next_in, z.avail_in);
+        unsigned got;
+        if (load(s, s->in.data() + z.avail_in, s->size - z.avail_in, &got) == -1) return -1;
+        z.avail_in += got;
+        z.next_in = s->in.data();
+    }
+    return 0;
+}
+
+int look(GzFile *s)                                     /* gz_look, gzread.c:86-165 */
+{
+    z_stream &z = s->strm;
+    if (s->size == 0) {
+        try { s->in.resize(s->want); s->out.resize((size_t)s->want << 1); }
+        catch (...) { s->in.clear(); s->out.clear(); set_error(s, Z_MEM_ERROR, "out of memory"); return -1; }
+        s->size = s->want;
+        z.zalloc = Z_NULL; z.zfree = Z_NULL; z.opaque = Z_NULL; z.avail_in = 0; z.next_in = Z_NULL;
+        if (inflateInit2(&z, 15 + 16) != Z_OK) {
+            s->in.clear(); s->out.clear(); s->size = 0;
+            set_error(s, Z_MEM_ERROR, "out of memory");
+            return -1;
+        }
+    }
+    if (z.avail_in < 2) {
+        if (refill(s) == -1) return -1;
+        if (z.avail_in == 0) return 0;
+    }
+    if (z.avail_in > 1 && z.next_in[0] == 31 && z.next_in[1] == 139) {
+        inflateReset(&z);
+        s->how = GZIP; s->direct = 0;
+        return 0;
+    }
+    if (s->direct == 0) {                               /* bytes behind a gzip stream that are no gzip stream: ignored */
+        z.avail_in = 0; s->eof = 1; s->x.have = 0;
+        return 0;
+    }
+    s->x.next = s->out.data();                          /* not gzip at all: hand the bytes through */
+    if (z.avail_in) { memcpy(s->x.next, z.next_in, z.avail_in); s->x.have = z.avail_in; z.avail_in = 0; }
+    s->how = COPY; s->direct = 1;
+    return 0;
+}
+
+int decomp(GzFile *s)                                   /* gz_decomp, gzread.c:172-218 */
+{
+    z_stream &z = s->strm;
+    int ret = Z_OK;
+    const unsigned had = z.avail_out;
+    do {
+        if (z.avail_in == 0 && refill(s) == -1) return -1;
+        /* inflate() of this library takes input ahead of its output, so an empty input buffer at the end of
+         * the file is the end of the data only once inflate() itself has nothing left to hand over */
+        const bool starved = z.avail_in == 0;
+        ret = inflate(&z, Z_NO_FLUSH);
+        if (starved && ret == Z_BUF_ERROR) { set_error(s, Z_BUF_ERROR, "unexpected end of file"); break; }
+        if (ret == Z_STREAM_ERROR || ret == Z_NEED_DICT) { set_error(s, Z_STREAM_ERROR, "internal error: inflate stream corrupt"); return -1; }
+        if (ret == Z_MEM_ERROR) { set_error(s, Z_MEM_ERROR, "out of memory"); return -1; }
+        if (ret == Z_DATA_ERROR) { set_error(s, Z_DATA_ERROR, z.msg == NULL ? "compressed data error" : z.msg); return -1; }
+    } while (z.avail_out && ret != Z_STREAM_END);
+    s->x.have = had - z.avail_out;
+    s->x.next = z.next_out - s->x.have;
+    if (ret == Z_STREAM_END) s->how = LOOK;             /* another member may follow */
+    return 0;
+}
+
+int fetch(GzFile *s)                                    /* gz_fetch, gzread.c:226-253 */
+{
+    z_stream &z = s->strm;
+    do {
+        switch (s->how) {
+        case LOOK:
+            if (look(s) == -1) return -1;
+            if (s->how == LOOK) return 0;
+            break;
+        case COPY:
+            if (load(s, s->out.data(), s->size << 1, &s->x.have) == -1) return -1;
+            s->x.next = s->out.data();
+            return 0;
+        case GZIP:
+            z.avail_out = s->size << 1; z.next_out = s->out.data();
+            if (decomp(s) == -1) return -1;
+        }
+    } while (s->x.have == 0 && (!s->eof || z.avail_in));
+    return 0;
+}
+
+/* Nothing more can come: the file is read, the input buffer is empty, and no gzip member is open inside
+ * inflate() (or the open one has already been found cut short). */
+inline bool at_end(const GzFile *s) { return s->eof && s->strm.avail_in == 0 && (s->how != GZIP || s->err == Z_BUF_ERROR); }
+
+int skip_out(GzFile *s, z_off64_t len)                  /* gz_skip, gzread.c:256-285 */
+{
+    while (len) {
+        if (s->x.have) {
+            unsigned n = (z_off64_t)s->x.have > len ? (unsigned)len : s->x.have;
+            s->x.have -= n; s->x.next += n; s->x.pos += n; len -= n;
+        } else if (at_end(s)) break;
+        else if (fetch(s) == -1) return -1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ writing */
+int winit(GzFile *s)                                    /* gz_init, gzwrite.c:15-66 */
+{
+    z_stream &z = s->strm;
+    try { s->in.resize(s->want); if (!s->direct) s->out.resize(s->want); }
+    catch (...) { s->in.clear(); s->out.clear(); set_error(s, Z_MEM_ERROR, "out of memory"); return -1; }
+    if (!s->direct) {
+        z.zalloc = Z_NULL; z.zfree = Z_NULL; z.opaque = Z_NULL;
+        if (deflateInit2(&z, s->level, Z_DEFLATED, 15 + 16, 8, s->strategy) != Z_OK) {
+            s->in.clear(); s->out.clear();
+            set_error(s, Z_MEM_ERROR, "out of memory");
+            return -1;
+        }
+    }
+    s->size = s->want;
+    if (!s->direct) { z.avail_out = s->size; z.next_out = s->out.data(); s->x.next = z.next_out; }
+    return 0;
+}
+
+int write_all(GzFile *s, const unsigned char *p, size_t n)
+{
+    while (n) {
+        ssize_t w = write(s->fd, p, n);
+        if (w < 0) { if (errno == EINTR) continue; set_error(s, Z_ERRNO, strerror(errno)); return -1; }
+        p += w; n -= (size_t)w;
+    }
+    return 0;
+}
+
+int comp(GzFile *s, int flush)                          /* gz_comp, gzwrite.c:74-131 */
+{
+    z_stream &z = s->strm;
+    if (s->size == 0 && winit(s) == -1) return -1;
+    if (s->direct) {
+        if (write_all(s, z.next_in, z.avail_in) == -1) return -1;
+        z.avail_in = 0;
+        return 0;
+    }
+    int ret = Z_OK;
+    unsigned made;
+    do {
+        /* the buffer goes out when it is full, and on a flush (for Z_FINISH: once the stream has ended) */
+        if (z.avail_out == 0 || (flush != Z_NO_FLUSH && (flush != Z_FINISH || ret == Z_STREAM_END))) {
+            size_t have = (size_t)(z.next_out - s->x.next);
+            if (have && write_all(s, s->x.next, have) == -1) return -1;
+            if (z.avail_out == 0) { z.avail_out = s->size; z.next_out = s->out.data(); }
+            s->x.next = z.next_out;
+        }
+        made = z.avail_out;
+        ret = deflate(&z, flush);
+        if (ret == Z_STREAM_ERROR) { set_error(s, Z_STREAM_ERROR, "internal error: deflate stream corrupt"); return -1; }
+        made -= z.avail_out;
+    } while (made);
+    if (flush == Z_FINISH) deflateReset(&z);            /* the next write starts a new member */
+    return 0;
+}
+
+int zeros(GzFile *s, z_off64_t len)                     /* gz_zero, gzwrite.c:134-162 */
+{
+    z_stream &z = s->strm;
+    if (z.avail_in && comp(s, Z_NO_FLUSH) == -1) return -1;
+    bool first = true;
+    while (len) {
+        unsigned n = (z_off64_t)s->size > len ? (unsigned)len : s->size;
+        if (first) { memset(s->in.data(), 0, n); first = false; }
+        z.avail_in = n; z.next_in = s->in.data();
+        s->x.pos += n;
+        if (comp(s, Z_NO_FLUSH) == -1) return -1;
+        len -= n;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+gzFile gzopen(const char *path, const char *mode) { return open_file(path, -1, mode); }       /* gzlib.c:268 */
+gzFile gzopen64(const char *path, const char *mode) { return open_file(path, -1, mode); }     /* gzlib.c:276 */
+
+gzFile gzdopen(int fd, const char *mode)                                                        /* gzlib.c:284-301 */
+{
+    if (fd == -1) return NULL;
+    char name[32];
+    snprintf(name, sizeof name, "<fd:%d>", fd);
+    return open_file(name, fd, mode);
+}
+
+int gzbuffer(gzFile file, unsigned size)                                                        /* gzlib.c:314-336 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return -1;
+    if (s->size != 0) return -1;                        /* too late: buffers exist */
+    if (size < 2) size = 2;
+    if ((size << 1) < size) return -1;                  /* the read side needs twice as much */
+    s->want = size;
+    return 0;
+}
+
+int gzrewind(gzFile file)                                                                       /* gzlib.c:339-359 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
+    if (lseek(s->fd, s->start, SEEK_SET) == -1) return -1;
+    reset(s);
+    return 0;
+}
+
+z_off64_t gzseek64(gzFile file, z_off64_t offset, int whence)                                   /* gzlib.c:362-436 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE) || fatal(s)) return -1;
+    if (whence != SEEK_SET && whence != SEEK_CUR) return -1;
+    if (whence == SEEK_SET) offset -= s->x.pos;
+    else if (s->seek) offset += s->skip;
+    s->seek = 0;
+    if (s->mode == GZ_READ && s->how == COPY && s->x.pos + offset >= 0) {      /* plain file: seek the descriptor */
+        if (lseek(s->fd, offset - s->x.have, SEEK_CUR) == -1) return -1;
+        s->x.have = 0; s->eof = 0; s->past = 0; s->seek = 0;
+        set_error(s, Z_OK, NULL);
+        s->strm.avail_in = 0;
+        s->x.pos += offset;
+        return s->x.pos;
+    }
+    if (offset < 0) {                                   /* backwards: only by reading again from the start */
+        if (s->mode != GZ_READ) return -1;
+        offset += s->x.pos;
+        if (offset < 0) return -1;
+        if (gzrewind(file) == -1) return -1;
+    }
+    if (s->mode == GZ_READ) {
+        unsigned n = (z_off64_t)s->x.have > offset ? (unsigned)offset : s->x.have;
+        s->x.have -= n; s->x.next += n; s->x.pos += n; offset -= n;
+    }
+    if (offset) { s->seek = 1; s->skip = offset; }
+    return s->x.pos + offset;
+}
+
+z_off_t gzseek(gzFile file, z_off_t offset, int whence)
+{
+    z_off64_t r = gzseek64(file, (z_off64_t)offset, whence);
+    return r == (z_off_t)r ? (z_off_t)r : -1;
+}
+
+z_off64_t gztell64(gzFile file)                                                                 /* gzlib.c:451-465 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return -1;
+    return s->x.pos + (s->seek ? s->skip : 0);
+}
+z_off_t gztell(gzFile file) { z_off64_t r = gztell64(file); return r == (z_off_t)r ? (z_off_t)r : -1; }
+
+z_off64_t gzoffset64(gzFile file)                                                               /* gzlib.c:478-498 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return -1;
+    z_off64_t off = lseek(s->fd, 0, SEEK_CUR);
+    if (off == -1) return -1;
+    if (s->mode == GZ_READ) off -= s->strm.avail_in;
+    return off;
+}
+z_off_t gzoffset(gzFile file) { z_off64_t r = gzoffset64(file); return r == (z_off_t)r ? (z_off_t)r : -1; }
+
+int gzeof(gzFile file)                                                                          /* gzlib.c:511-525 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return 0;
+    return s->mode == GZ_READ ? s->past : 0;
+}
+
+const char *gzerror(gzFile file, int *errnum)                                                   /* gzlib.c:528-546 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return NULL;
+    if (errnum != NULL) *errnum = s->err;
+    return s->err == Z_MEM_ERROR ? "out of memory" : s->msg.c_str();
+}
+
+void gzclearerr(gzFile file)                                                                    /* gzlib.c:549-567 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return;
+    if (s->mode == GZ_READ) { s->eof = 0; s->past = 0; }
+    set_error(s, Z_OK, NULL);
+}
+
+/* ------------------------------------------------------------------ gzread.c */
+int gzread(gzFile file, voidp buf, unsigned len)                                                /* gzread.c:288-379 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
+    if ((int)len < 0) { set_error(s, Z_DATA_ERROR, "requested length does not fit in int"); return -1; }
+    if (len == 0) return 0;
+    if (s->seek) { s->seek = 0; if (skip_out(s, s->skip) == -1) return -1; }
+    z_stream &z = s->strm;
+    unsigned got = 0, n;
+    do {
+        if (s->x.have) {                                /* what is already inflated */
+            n = s->x.have > len ? len : s->x.have;
+            memcpy(buf, s->x.next, n);
+            s->x.next += n; s->x.have -= n;
+        } else if (at_end(s)) { s->past = 1; break; }
+        else if (s->how == LOOK || len < (s->size << 1)) {      /* small request or new member: through the buffer */
+            if (fetch(s) == -1) return -1;
+            continue;
+        } else if (s->how == COPY) {                            /* large request: straight into the caller's memory */
+            if (load(s, (unsigned char *)buf, len, &n) == -1) return -1;
+        } else {
+            z.avail_out = len; z.next_out = (Bytef *)buf;
+            if (decomp(s) == -1) return -1;
+            n = s->x.have; s->x.have = 0;
+        }
+        len -= n; buf = (char *)buf + n; got += n; s->x.pos += n;
+    } while (len);
+    return (int)got;
+}
+
+#undef gzgetc
+int gzgetc(gzFile file)                                                                         /* gzread.c:387-414 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
+    if (s->x.have) { s->x.have--; s->x.pos++; return *(s->x.next)++; }
+    unsigned char c;
+    return gzread(file, &c, 1) < 1 ? -1 : c;
+}
+int gzgetc_(gzFile file) { return gzgetc(file); }
+
+int gzungetc(int c, gzFile file)                                                                /* gzread.c:423-480 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
+    if (s->seek) { s->seek = 0; if (skip_out(s, s->skip) == -1) return -1; }
+    if (c < 0) return -1;
+    if (s->size == 0 && look(s) == -1) return -1;       /* the buffers must exist before a byte can be parked in them */
+    unsigned char *const out = s->out.data();
+    const size_t cap = (size_t)s->size << 1;
+    if (s->x.have == 0) {                               /* empty: the byte goes to the very end, room for more in front */
+        s->x.have = 1; s->x.next = out + cap - 1; s->x.next[0] = (unsigned char)c;
+        s->x.pos--; s->past = 0;
+        return c;
+    }
+    if (s->x.have == cap) { set_error(s, Z_DATA_ERROR, "out of room to push characters"); return -1; }
+    if (s->x.next == out) {                             /* slide the data to the end of the buffer */
+        memmove(out + cap - s->x.have, out, s->x.have);
+        s->x.next = out + cap - s->x.have;
+    }
+    s->x.have++; s->x.next--; s->x.next[0] = (unsigned char)c;
+    s->x.pos--; s->past = 0;
+    return c;
+}
+
+char *gzgets(gzFile file, char *buf, int len)                                                   /* gzread.c:483-544 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || buf == NULL || len < 1) return NULL;
+    if (s->mode != GZ_READ || fatal(s)) return NULL;
+    if (s->seek) { s->seek = 0; if (skip_out(s, s->skip) == -1) return NULL; }
+    char *str = buf;
+    unsigned left = (unsigned)len - 1;
+    const unsigned char *eol = NULL;
+    while (left && eol == NULL) {
+        if (s->x.have == 0 && fetch(s) == -1) return NULL;
+        if (s->x.have == 0) { s->past = 1; break; }
+        unsigned n = s->x.have > left ? left : s->x.have;
+        eol = (const unsigned char *)memchr(s->x.next, '\n', n);
+        if (eol != NULL) n = (unsigned)(eol - s->x.next) + 1;
+        memcpy(buf, s->x.next, n);
+        s->x.have -= n; s->x.next += n; s->x.pos += n; left -= n; buf += n;
+    }
+    if (buf == str) return NULL;
+    buf[0] = 0;
+    return str;
+}
+
+int gzdirect(gzFile file)                                                                       /* gzread.c:547-564 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL) return 0;
+    if (s->mode == GZ_READ && s->how == LOOK && s->x.have == 0) (void)look(s);
+    return s->direct;
+}
+
+int gzclose_r(gzFile file)                                                                      /* gzread.c:567-594 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL) return Z_STREAM_ERROR;
+    if (s->mode != GZ_READ) return Z_STREAM_ERROR;
+    if (s->size) inflateEnd(&s->strm);
+    int err = s->err == Z_BUF_ERROR ? Z_BUF_ERROR : Z_OK;
+    int ret = close(s->fd);
+    delete s;
+    return ret ? Z_ERRNO : err;
+}
+
+/* ------------------------------------------------------------------ gzwrite.c */
+int gzwrite(gzFile file, const void *buf, unsigned len)                                         /* gzwrite.c:165-243 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return 0;
+    if ((int)len < 0) { set_error(s, Z_DATA_ERROR, "requested length does not fit in int"); return 0; }
+    if (len == 0) return 0;
+    if (s->size == 0 && winit(s) == -1) return 0;
+    if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return 0; }
+    z_stream &z = s->strm;
+    const unsigned put = len;
+    if (len < s->size) {                                /* collect small writes in the input buffer */
+        do {
+            if (z.avail_in == 0) z.next_in = s->in.data();
+            unsigned have = (unsigned)((z.next_in + z.avail_in) - s->in.data());
+            unsigned copy = s->size - have;
+            if (copy > len) copy = len;
+            memcpy(s->in.data() + have, buf, copy);
+            z.avail_in += copy; s->x.pos += copy;
+            buf = (const char *)buf + copy; len -= copy;
+            if (len && comp(s, Z_NO_FLUSH) == -1) return 0;
+        } while (len);
+    } else {                                            /* large writes are compressed from the caller's memory */
+        if (z.avail_in && comp(s, Z_NO_FLUSH) == -1) return 0;
+        z.avail_in = len; z.next_in = (const Bytef *)buf;
+        s->x.pos += len;
+        if (comp(s, Z_NO_FLUSH) == -1) return 0;
+    }
+    return (int)put;
+}
+
+int gzputc(gzFile file, int c)                                                                  /* gzwrite.c:246-291 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return -1;
+    unsigned char b = (unsigned char)c;
+    return gzwrite(file, &b, 1) != 1 ? -1 : (c & 0xff);
+}
+
+int gzputs(gzFile file, const char *str)                                                        /* gzwrite.c:294-305 */
+{
+    unsigned len = (unsigned)strlen(str);
+    int ret = gzwrite(file, str, len);
+    return ret == 0 && len != 0 ? -1 : ret;
+}
+
+int gzvprintf(gzFile file, const char *format, va_list va)                                      /* gzwrite.c:311-373 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return 0;
+    if (s->size == 0 && winit(s) == -1) return 0;
+    if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return 0; }
+    z_stream &z = s->strm;
+    if (z.avail_in && comp(s, Z_NO_FLUSH) == -1) return 0;
+    int size = (int)(s->size > (unsigned)INT_MAX ? INT_MAX : s->size);
+    s->in[size - 1] = 0;
+    int len = vsnprintf((char *)s->in.data(), (size_t)size, format, va);
+    if (len <= 0 || len >= size || s->in[size - 1] != 0) return 0;      /* what does not fit the buffer is not written */
+    z.avail_in = (unsigned)len; z.next_in = s->in.data();
+    s->x.pos += len;
+    return len;
+}
+
+int gzprintf(gzFile file, const char *format, ...)                                              /* gzwrite.c:375-385 */
+{
+    va_list va;
+    va_start(va, format);
+    int ret = gzvprintf(file, format, va);
+    va_end(va);
+    return ret;
+}
+
+int gzflush(gzFile file, int flush)                                                             /* gzwrite.c:478-510 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL) return -1;
+    if (s->mode != GZ_WRITE || s->err != Z_OK) return Z_STREAM_ERROR;
+    if (flush < 0 || flush > Z_FINISH) return Z_STREAM_ERROR;
+    if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return -1; }
+    comp(s, flush);
+    return s->err;
+}
+
+int gzsetparams(gzFile file, int level, int strategy)                                           /* gzwrite.c:513-552 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL) return Z_STREAM_ERROR;
+    if (s->mode != GZ_WRITE || s->err != Z_OK) return Z_STREAM_ERROR;
+    if (level == s->level && strategy == s->strategy) return Z_OK;
+    if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return -1; }
+    if (s->size) {
+        if (s->strm.avail_in && comp(s, Z_PARTIAL_FLUSH) == -1) return s->err;
+        deflateParams(&s->strm, level, strategy);
+    }
+    s->level = level; s->strategy = strategy;
+    return Z_OK;
+}
+
+int gzclose_w(gzFile file)                                                                      /* gzwrite.c:555-577 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL) return Z_STREAM_ERROR;
+    if (s->mode != GZ_WRITE) return Z_STREAM_ERROR;
+    int ret = Z_OK;
+    if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) ret = s->err; }
+    if (comp(s, Z_FINISH) == -1) ret = s->err;
+    if (s->size && !s->direct) (void)deflateEnd(&s->strm);
+    if (close(s->fd) == -1) ret = Z_ERRNO;
+    delete s;
+    return ret;
+}
+
+int gzclose(gzFile file)                                                                        /* gzclose.c:11-25 */
+{
+    GzFile *s = gz(file);
+    if (s == NULL) return Z_STREAM_ERROR;
+    return s->mode == GZ_READ ? gzclose_r(file) : gzclose_w(file);
+}
+
+}  // extern "C"
