@@ -138,6 +138,16 @@ long inflateMark(z_streamp strm);                                               
  * it has been handed over; Z_STREAM_ERROR otherwise. */
 int inflatePrime(z_streamp strm, int bits, int value);                                              /* :230 */
 
+/* call-back interface for raw deflate data: infback.c:28-640.  Unused input is reported in next_in/avail_in
+ * as far as it lies in the last buffer in() delivered. */
+typedef unsigned (*in_func)(void *, const unsigned char **);
+typedef int (*out_func)(void *, unsigned char *, unsigned);
+int inflateBackInit_(z_streamp strm, int windowBits, unsigned char *window, const char *version, int stream_size);    /* :28 */
+int inflateBack(z_streamp strm, in_func in, void *in_desc, out_func out, void *out_desc);                             /* :250 */
+int inflateBackEnd(z_streamp strm);                                                                                  /* :631 */
+#define inflateBackInit(strm, windowBits, window) \
+    inflateBackInit_((strm), (windowBits), (window), ZLIB_VERSION, (int)sizeof(z_stream))
+
 /* one-shot utilities: compress.c:22-80, uncompr.c:24-59 */
 int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen);
 int compress2(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen, int level);

@@ -12,6 +12,8 @@ Z_STREAM_ERROR, Z_DATA_ERROR, Z_MEM_ERROR, Z_BUF_ERROR, Z_VERSION_ERROR = -2, -3
 
 ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint, C.c_uint)
 FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+IN_FUNC = C.CFUNCTYPE(C.c_uint, C.c_void_p, C.POINTER(C.c_void_p))        # zlib.h:1003-1004
+OUT_FUNC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint)
 
 
 class ZStream(C.Structure):        # zlib.h:85-104
@@ -72,6 +74,9 @@ def lib():
         for name in ("adler32_combine", "crc32_combine", "adler32_combine64", "crc32_combine64"):
             getattr(l, name).argtypes = [C.c_ulong, C.c_ulong, C.c_long]; getattr(l, name).restype = C.c_ulong
         l.get_crc_table.restype = C.POINTER(C.c_uint)
+        l.inflateBackInit_.argtypes = [P, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        l.inflateBack.argtypes = [P, IN_FUNC, C.c_void_p, OUT_FUNC, C.c_void_p]
+        l.inflateBackEnd.argtypes = [P]
         # gz* file layer (zlib.h:1224-1552)
         G = C.c_void_p
         for name in ("gzopen", "gzopen64"):

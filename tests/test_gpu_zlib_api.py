@@ -4,6 +4,8 @@ gzip headers, error returns.  The system zlib (Python's) is the independent read
 import ctypes as C
 import gzip
 import io
+import json
+import os
 import zlib
 
 import pytest
@@ -377,3 +379,56 @@ def test_deflate_prime_puts_bits_in_front():
         assert l.inflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
         assert back.raw[:s.total_out] == data
         assert l.inflateEnd(C.byref(s)) == Z.Z_OK
+
+
+def _inflate_back(stream, piece, fail_output=False):
+    """inflateBack over `stream`, handed out by the in() call-back `piece` bytes at a time."""
+    l = Z.lib()
+    s = Z.ZStream()
+    win = C.create_string_buffer(32768)
+    assert l.inflateBackInit_(C.byref(s), 15, win, Z.VERSION, Z.SZ) == Z.Z_OK
+    src = C.create_string_buffer(stream, max(len(stream), 1))
+    state = {"pos": 0}
+    got = bytearray()
+
+    def pull(desc, bufp):
+        n = min(piece, len(stream) - state["pos"])
+        if n:
+            bufp[0] = C.addressof(src) + state["pos"]
+            state["pos"] += n
+        return n
+
+    def push(desc, buf, n):
+        got.extend(C.string_at(buf, n))
+        return 1 if fail_output else 0
+
+    rc = l.inflateBack(C.byref(s), Z.IN_FUNC(pull), None, Z.OUT_FUNC(push), None)
+    msg, left = s.msg, s.avail_in
+    assert l.inflateBackEnd(C.byref(s)) == Z.Z_OK
+    return rc, bytes(got), msg, left
+
+
+def test_inflate_back_call_back_interface():
+    """infback.c through the cases of the reference's test (test/infcover.c:470-504, 507-560)."""
+    l = Z.lib()
+    win = C.create_string_buffer(32768)
+    assert l.inflateBackInit_(None, 0, win, None, 0) == Z.Z_VERSION_ERROR
+    assert l.inflateBackInit_(None, 0, win, Z.VERSION, Z.SZ) == Z.Z_STREAM_ERROR
+    assert l.inflateBackEnd(None) == Z.Z_STREAM_ERROR
+    s = Z.ZStream()
+    assert l.inflateBackInit_(C.byref(s), 7, win, Z.VERSION, Z.SZ) == Z.Z_STREAM_ERROR
+    assert _inflate_back(bytes([3, 0]), 2)[0] == Z.Z_STREAM_END
+    data = O.corpus(500000, 4, 111)
+    raw = O.deflate_chunked(data, 131072, 6, 0, 8)[0]
+    for piece in (len(raw) + 10, 65536, 1000):
+        rc, got, msg, left = _inflate_back(raw + b"xyz", piece)
+        assert rc == Z.Z_STREAM_END and got == data
+    assert _inflate_back(raw, 1 << 20)[3] == 0 and _inflate_back(raw + b"xyz", 1 << 20)[3] == 3      # unused input is handed back
+    assert _inflate_back(raw[:len(raw) // 2], 65536)[0] == Z.Z_BUF_ERROR                               # in() runs dry
+    assert _inflate_back(raw, 65536, fail_output=True)[0] == Z.Z_BUF_ERROR                             # out() fails
+    vec = json.load(open(os.path.join(Z.ROOT, "tests", "golden", "inflate_vectors.json")))["raw"]
+    for v in vec:
+        rc, got, msg, left = _inflate_back(bytes.fromhex(v["hex"].replace(" ", "")), 1 << 16)
+        assert rc != Z.Z_STREAM_ERROR
+        if v["msg"] is not None:
+            assert rc == Z.Z_DATA_ERROR and msg == v["msg"].encode(), (v, rc, msg)

@@ -1111,4 +1111,72 @@ const z_crc_t *get_crc_table(void) {      // crc32.c:190-199: the byte-wise tabl
     return table;
 }
 
+// ------------------------------------------------------------------ inflateBack (infback.c:28-640)
+// The call-back flavour of inflate for raw deflate data: input is pulled with in(), output is handed
+// to out() a window at a time.  Here it is a loop around inflate() of this library; the caller's
+// window is the output buffer of every inflate() call.
+namespace {
+const uint32_t BACK_MAGIC = 0x5a414d42u;
+struct BState { uint32_t magic; unsigned char *window; unsigned wsize; };
+}
+
+int inflateBackInit_(z_streamp strm, int windowBits, unsigned char *window, const char *version, int stream_size) {   // infback.c:28-72
+    if (version == Z_NULL || version[0] != ZLIB_VERSION[0] || stream_size != (int)sizeof(z_stream)) return Z_VERSION_ERROR;
+    if (strm == Z_NULL || window == Z_NULL || windowBits < 8 || windowBits > 15) return Z_STREAM_ERROR;
+    strm->msg = Z_NULL;
+    if (strm->zalloc == (alloc_func)0) { strm->zalloc = default_alloc; strm->opaque = (voidpf)0; }
+    if (strm->zfree == (free_func)0) strm->zfree = default_free;
+    BState *b = (BState *)strm->zalloc(strm->opaque, 1, (uInt)sizeof(BState));
+    if (b == Z_NULL) return Z_MEM_ERROR;
+    b->magic = BACK_MAGIC; b->window = window; b->wsize = 1u << windowBits;
+    strm->state = (struct internal_state *)b;
+    return Z_OK;
+}
+
+int inflateBack(z_streamp strm, in_func in, void *in_desc, out_func out, void *out_desc) {             // infback.c:250-629
+    if (strm == Z_NULL || strm->state == Z_NULL || ((BState *)strm->state)->magic != BACK_MAGIC) return Z_STREAM_ERROR;
+    BState *b = (BState *)strm->state;
+    strm->msg = Z_NULL;
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2_(&z, -15, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) return Z_MEM_ERROR;
+    z.next_in = strm->next_in; z.avail_in = strm->next_in != Z_NULL ? strm->avail_in : 0;
+    z.next_out = b->window; z.avail_out = b->wsize;
+    int ret;
+    for (;;) {
+        if (z.avail_in == 0) {
+            const unsigned char *p = Z_NULL;
+            unsigned n = in(in_desc, &p);
+            if (n != 0) { z.next_in = p; z.avail_in = n; }
+        }
+        const bool starved = z.avail_in == 0;
+        ret = inflate(&z, Z_NO_FLUSH);
+        if (ret == Z_DATA_ERROR || ret == Z_MEM_ERROR || ret == Z_NEED_DICT || ret == Z_STREAM_ERROR) {
+            strm->msg = z.msg;
+            if (ret == Z_NEED_DICT || ret == Z_STREAM_ERROR) ret = Z_DATA_ERROR;
+            break;
+        }
+        if (z.avail_out == 0 || ret == Z_STREAM_END) {          // a full window, or what is left at the end
+            unsigned have = b->wsize - z.avail_out;
+            if (have && out(out_desc, b->window, have)) { ret = Z_BUF_ERROR; break; }
+            z.next_out = b->window; z.avail_out = b->wsize;
+        }
+        if (ret == Z_STREAM_END) break;
+        if (starved && ret == Z_BUF_ERROR) { z.next_in = Z_NULL; z.avail_in = 0; break; }     // in() has nothing more: infback.c:117-124
+    }
+    strm->next_in = z.next_in; strm->avail_in = z.avail_in;     // what the stream did not use
+    z.msg = Z_NULL;
+    inflateEnd(&z);
+    return ret;
+}
+
+int inflateBackEnd(z_streamp strm) {                                                                    // infback.c:631-640
+    if (strm == Z_NULL || strm->state == Z_NULL || strm->zfree == (free_func)0 || ((BState *)strm->state)->magic != BACK_MAGIC)
+        return Z_STREAM_ERROR;
+    ((BState *)strm->state)->magic = 0;
+    strm->zfree(strm->opaque, strm->state);
+    strm->state = Z_NULL;
+    return Z_OK;
+}
+
 }  // extern "C"
