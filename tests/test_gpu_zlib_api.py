@@ -432,3 +432,86 @@ def test_inflate_back_call_back_interface():
         assert rc != Z.Z_STREAM_ERROR
         if v["msg"] is not None:
             assert rc == Z.Z_DATA_ERROR and msg == v["msg"].encode(), (v, rc, msg)
+
+
+def test_state_goes_through_the_callers_allocator():
+    """zalloc/zfree hooks (deflate.c:240-253, 277, 997-1003; the bookkeeping idea of test/infcover.c:55-234):
+    every block comes from the caller's allocator and goes back to it; a failing allocator is Z_MEM_ERROR."""
+    l = Z.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    live, stats = set(), {"allocs": 0, "fail": False}
+
+    def zalloc(opaque, items, size):
+        if stats["fail"]:
+            return None
+        p = libc.malloc(items * size)
+        live.add(p); stats["allocs"] += 1
+        return p
+
+    def zfree(opaque, p):
+        live.discard(p)
+        libc.free(p)
+
+    za, zf = Z.ALLOC(zalloc), Z.FREE(zfree)
+    data = O.corpus(200000, 0, 121)
+    src = C.create_string_buffer(data, len(data))
+    obuf = C.create_string_buffer(len(data) + 4096)
+    s = Z.ZStream()
+    s.zalloc, s.zfree = C.cast(za, C.c_void_p), C.cast(zf, C.c_void_p)
+    assert l.deflateInit2_(C.byref(s), 6, 8, 15, 8, 0, Z.VERSION, Z.SZ) == Z.Z_OK
+    assert stats["allocs"] >= 1 and live
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(data), C.addressof(obuf), len(data) + 4096
+    d = Z.ZStream()
+    assert l.deflateCopy(C.byref(d), C.byref(s)) == Z.Z_OK               # the copy's state comes from the same hooks
+    assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+    packed = obuf.raw[:s.total_out]
+    assert l.deflateEnd(C.byref(s)) == Z.Z_OK and l.deflateEnd(C.byref(d)) == Z.Z_OK
+    assert not live
+    i = Z.ZStream()
+    i.zalloc, i.zfree = C.cast(za, C.c_void_p), C.cast(zf, C.c_void_p)
+    assert l.inflateInit2_(C.byref(i), 15, Z.VERSION, Z.SZ) == Z.Z_OK and live
+    psrc = C.create_string_buffer(packed, len(packed))
+    back = C.create_string_buffer(len(data) + 16)
+    i.next_in, i.avail_in, i.next_out, i.avail_out = C.addressof(psrc), len(packed), C.addressof(back), len(data) + 16
+    assert l.inflate(C.byref(i), Z.Z_FINISH) == Z.Z_STREAM_END and back.raw[:i.total_out] == data
+    assert l.inflateEnd(C.byref(i)) == Z.Z_OK and not live
+    stats["fail"] = True
+    for init in (lambda z: l.deflateInit2_(C.byref(z), 6, 8, 15, 8, 0, Z.VERSION, Z.SZ), lambda z: l.inflateInit2_(C.byref(z), 15, Z.VERSION, Z.SZ)):
+        z = Z.ZStream()
+        z.zalloc, z.zfree = C.cast(za, C.c_void_p), C.cast(zf, C.c_void_p)
+        assert init(z) == Z.Z_MEM_ERROR and not z.state
+
+
+def test_streams_of_different_threads():
+    """Distinct streams may be used from different threads at once (zlib.h:143-145); the one GPU engine behind
+    them is shared under a lock."""
+    import threading
+    l = Z.lib()
+    results = {}
+
+    def work(k):
+        try:
+            data = O.corpus(700000 + 12345 * k, k % 5, 130 + k)
+            for rep in range(3):
+                cap = C.c_ulong(l.compressBound(len(data)))
+                out = C.create_string_buffer(cap.value)
+                assert l.compress2(out, C.byref(cap), data, len(data), 1 + (k + rep) % 9) == Z.Z_OK
+                assert zlib.decompress(out.raw[:cap.value]) == data
+                n = C.c_ulong(len(data))
+                back = C.create_string_buffer(len(data))
+                assert l.uncompress(back, C.byref(n), out.raw[:cap.value], cap.value) == Z.Z_OK and back.raw == data
+                rc, got, msg, unused, _ = Z.inflate_stream(zlib.compress(data, 6), 15, in_step=50000, out_step=200000)
+                assert rc == Z.Z_STREAM_END and got == data
+                assert l.crc32(0, data, len(data)) == zlib.crc32(data)
+            results[k] = True
+        except BaseException as e:          # noqa: BLE001 - reported by the main thread
+            results[k] = e
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert all(results.get(k) is True for k in range(6)), results
