@@ -154,6 +154,11 @@ typedef struct zamd_inflate_seg {
 #define ZAMD_INF_EXACT    2u            /* out_len must come out equal to out_cap */
 int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, zamd_inflate_seg *segs, uint64_t nseg,
                               const void *d_head_window, void *d_out, uint64_t out_bytes);
+/* Offsets just behind every 00 00 FF FF in d_in[from, n) (the pattern inflateSync looks for,
+ * inflate.c:1354-1375): candidate starting points for zamd_inflate_segments_dev.  h_list (host)
+ * receives at most cap offsets in no particular order; *count above cap means the list is
+ * incomplete. */
+int zamd_find_sync_dev(zamd_engine *e, const void *d_in, uint64_t from, uint64_t n, uint64_t *h_list, uint32_t cap, uint32_t *count);
 const char *zamd_inflate_message(uint32_t status);      /* the reference's msg strings, inflate.c:859-1202 */
 int zamd_inflate_last_error(zamd_engine *e, int64_t *segment, uint32_t *status);
 

@@ -59,6 +59,8 @@ def load_library() -> C.CDLL:
     lib.zamd_deflate_shard_dev.restype = i32
     lib.zamd_engine_tune.argtypes = [vp, i32, i32, i32, i32]
     lib.zamd_engine_tune.restype = i32
+    lib.zamd_find_sync_dev.argtypes = [vp, vp, u64, u64, C.POINTER(u64), C.c_uint32, C.POINTER(C.c_uint32)]
+    lib.zamd_find_sync_dev.restype = i32
     lib.zamd_engine_prime.argtypes = [vp, i32, i32]
     lib.zamd_engine_prime.restype = i32
     lib.zamd_checksums_dev.argtypes = [vp, vp, u64, u32, vp, vp]

@@ -720,13 +720,14 @@ struct ZiState {
     uint32_t *d_marks = nullptr; uint32_t *d_mlist = nullptr;
     unsigned long long *d_res = nullptr;
     uint32_t last_status = 0; int64_t last_seg = -1;
+    uint64_t *d_scan = nullptr; uint32_t scan_cap = 0;          /* zamd_find_sync_dev's result list */
 };
 
 static void zi_free(zamd_engine *e)
 {
     ZiState *z = e->inf;
     if (!z) return;
-    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res);
+    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res); hipFree(z->d_scan);
     delete z; e->inf = nullptr;
 }
 
@@ -863,6 +864,49 @@ extern "C" int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uin
     rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad, regular);
     if (rc != ZAMD_OK && rc != ZAMD_DATA_ERROR) return rc;
     HIPCHK(hipMemcpy(segs, e->inf->d_segs, nseg * sizeof(ZiSeg), hipMemcpyDeviceToHost));
+    return ZAMD_OK;
+}
+
+/* Positions just behind every 00 00 FF FF in d_in[from, n): where a block may start after a sync marker
+ * (the pattern inflateSync looks for, inflate.c:1354-1375). */
+#define ZI_SCAN_PER_THREAD 16u
+__global__ __launch_bounds__(256) void k_inf_scan(const uint8_t *in, uint64_t from, uint64_t n, uint64_t *list, uint32_t cap, uint32_t *count)
+{
+    const uint64_t base = from + ((uint64_t)blockIdx.x * 256u + threadIdx.x) * ZI_SCAN_PER_THREAD;
+    if (base + 4 > n) return;
+    uint32_t w = (uint32_t)in[base] | ((uint32_t)in[base + 1] << 8) | ((uint32_t)in[base + 2] << 16);
+    for (uint32_t k = 0; k < ZI_SCAN_PER_THREAD && base + k + 4 <= n; k++) {
+        w |= (uint32_t)in[base + k + 3] << 24;
+        if (w == 0xffff0000u) { uint32_t i = atomicAdd(count, 1u); if (i < cap) list[i] = base + k + 4; }
+        w >>= 8;
+    }
+}
+
+extern "C" int zamd_find_sync_dev(zamd_engine *e, const void *d_in, uint64_t from, uint64_t n, uint64_t *h_list, uint32_t cap, uint32_t *count)
+{
+    if (!e || !d_in || !h_list || !count || from > n) return ZAMD_STREAM_ERROR;
+    *count = 0;
+    if (n - from < 4) return ZAMD_OK;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = zi_ensure(e, 1, 0, false);
+    if (rc) return rc;
+    ZiState *z = e->inf;
+    if (z->scan_cap < cap) {
+        hipFree(z->d_scan); z->d_scan = nullptr; z->scan_cap = 0;
+        if (hipMalloc((void **)&z->d_scan, (uint64_t)cap * 8) != hipSuccess) return ZAMD_MEM_ERROR;
+        z->scan_cap = cap;
+    }
+    hipStream_t s = e->st[0];
+    uint32_t *d_count = (uint32_t *)z->d_res;
+    HIPCHK(hipMemsetAsync(d_count, 0, 4, s));
+    const uint64_t threads = (n - from + ZI_SCAN_PER_THREAD - 1) / ZI_SCAN_PER_THREAD;
+    hipLaunchKernelGGL(k_inf_scan, dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s, (const uint8_t *)d_in, from, n, z->d_scan, cap, d_count);
+    HIPCHK(hipGetLastError());
+    uint32_t c = 0;
+    HIPCHK(hipMemcpyAsync(&c, d_count, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    *count = c;                                     /* more than cap: the list is incomplete, the caller falls back */
+    if (c && c <= cap) HIPCHK(hipMemcpy(h_list, z->d_scan, (uint64_t)c * 8, hipMemcpyDeviceToHost));
     return ZAMD_OK;
 }
 

@@ -15,7 +15,11 @@
 #include "../../include/zamd.h"
 #include "../../include/zamd_zlib.h"
 
+#include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -89,6 +93,18 @@ uint32_t header_crc(uint32_t crc, const uint8_t *p, size_t n) {
 const uint32_t DEFLATE_MAGIC = 0x5a414d44u;   // distinguishes our states from inflate states
 const uint32_t INFLATE_MAGIC = 0x5a414d49u;
 const uint32_t HIST = 32768;
+
+struct Trace {      // ZAMD_Z_TRACE=1: phase times of every engine round trip on stderr
+    bool on; std::chrono::steady_clock::time_point t; std::string line;
+    Trace() : on(getenv("ZAMD_Z_TRACE") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void lap(const char *what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        char b[64]; snprintf(b, sizeof b, " %s %.1f", what, std::chrono::duration<double, std::milli>(n - t).count());
+        line += b; t = n;
+    }
+    void done(const char *who) { if (on) fprintf(stderr, "zamd_z %s:%s\n", who, line.c_str()); }
+};
 
 enum { ST_INIT = 42, ST_BUSY = 113, ST_FINISH = 666 };   // deflate.h:51-57 values
 
@@ -192,8 +208,10 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, HIST + n + 64) != Z_OK) return Z_MEM_ERROR;
     if (grow(e, &g_gpu.d_out, &g_gpu.out_cap, bound + 64) != Z_OK) return Z_MEM_ERROR;
     int rc = 0;
+    Trace tr;
     if (head) rc = zamd_dev_upload(e, g_gpu.d_in + (HIST - head), s->hist.data() + (s->hist_len - head), head);
     if (rc == 0 && n) rc = zamd_dev_upload(e, g_gpu.d_in + HIST, src, n);
+    tr.lap("upload");
     uint64_t total = 0;
     if (rc == 0) {
         if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
@@ -203,12 +221,14 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
                                         s->mem_level, finish, g_gpu.d_out, bound, nullptr, &total);
         if (s->tuned) zamd_engine_tune(e, 0, 0, 0, 0);      // the engine is shared by all streams
     }
+    tr.lap("deflate");
     if (rc == 0 && s->wrap && n) {
         uint32_t v = (uint32_t)strm->adler;
         rc = s->wrap == 2 ? zamd_crc32_dev(e, v, g_gpu.d_in + HIST, n, &v)
                           : zamd_adler32_dev(e, v, g_gpu.d_in + HIST, n, &v);
         strm->adler = v;
     }
+    tr.lap("check");
     if (rc == 0 && total) {
         if (s->out.size() == s->out_pos && strm->avail_out >= total) {
             // nothing pending and room enough: straight into the caller's buffer
@@ -220,6 +240,7 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
             rc = zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, total);
         }
     }
+    tr.lap("download"); tr.done("deflate batch");
     if (rc != 0) return rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : (rc == ZAMD_BUF_ERROR ? Z_BUF_ERROR : Z_STREAM_ERROR);
     // history for the next batch = last 32 KiB of everything compressed since the last reset
     s->since_reset += n;
@@ -645,20 +666,38 @@ void idrain(z_streamp strm, IState *s) {
 // progress), Z_DATA_ERROR (msg set) or Z_MEM_ERROR.
 int decode_some(z_streamp strm, IState *s) {
     if (s->in.size() * 8ull <= s->bit_off) return Z_OK;
-    // sync-marker candidates: independent starting points for parallel wavefronts
+    Trace tr;
+    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    zamd_engine *e = engine_locked();
+    if (!e) return Z_MEM_ERROR;
+    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, s->in.size() + 64) != Z_OK) return Z_MEM_ERROR;
+    if (zamd_dev_upload(e, g_gpu.d_in, s->in.data(), s->in.size()) != 0) return Z_MEM_ERROR;
+    tr.lap("upload");
+    // sync-marker candidates: independent starting points for parallel wavefronts.  The bytes that are
+    // new since the last attempt are searched on the GPU (a marker may straddle the old end).
     {
-        static const uint8_t pat[4] = {0, 0, 0xff, 0xff};
-        const uint8_t *base = s->in.data(), *end = base + s->in.size();
-        const uint8_t *q = base + (s->scanned < 3 ? 0 : s->scanned - 3);     // a marker may straddle the old end
-        while (q + 4 <= end) {
-            const uint8_t *hit = (const uint8_t *)memmem(q, (size_t)(end - q), pat, 4);
-            if (!hit) break;
-            const uint64_t c = (uint64_t)(hit - base) + 4;
-            if (s->cands.empty() || s->cands.back() < c) s->cands.push_back(c);
-            q = hit + 1;
+        const uint64_t from = s->scanned < 3 ? 0 : s->scanned - 3;
+        std::vector<uint64_t> found(1u << 18);
+        uint32_t cnt = 0;
+        if (zamd_find_sync_dev(e, g_gpu.d_in, from, s->in.size(), found.data(), (uint32_t)found.size(), &cnt) != 0) return Z_MEM_ERROR;
+        if (cnt <= found.size()) {
+            found.resize(cnt);
+            std::sort(found.begin(), found.end());
+        } else {                                        // more markers than the list holds: search on the host
+            found.clear();
+            static const uint8_t pat[4] = {0, 0, 0xff, 0xff};
+            const uint8_t *base = s->in.data(), *end = base + s->in.size();
+            for (const uint8_t *q = base + from; q + 4 <= end;) {
+                const uint8_t *hit = (const uint8_t *)memmem(q, (size_t)(end - q), pat, 4);
+                if (!hit) break;
+                found.push_back((uint64_t)(hit - base) + 4);
+                q = hit + 1;
+            }
         }
+        for (uint64_t c : found) if (s->cands.empty() || s->cands.back() < c) s->cands.push_back(c);
         s->scanned = s->in.size();
     }
+    tr.lap("scan");
     std::vector<zamd_inflate_seg> segs;
     const uint64_t end_bits = s->in.size() * 8ull;
     // A candidate is a guess: what starts there may be the middle of a stored block, so its
@@ -674,13 +713,9 @@ int decode_some(z_streamp strm, IState *s) {
     add(s->bit_off, (uint32_t)s->hist.size(), false);
     for (uint64_t c : s->cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST, true);
 
-    std::lock_guard<std::mutex> lk(g_gpu.mu);
-    zamd_engine *e = engine_locked();
-    if (!e) return Z_MEM_ERROR;
-    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, s->in.size() + 64) != Z_OK) return Z_MEM_ERROR;
-    if (zamd_dev_upload(e, g_gpu.d_in, s->in.data(), s->in.size()) != 0) return Z_MEM_ERROR;
     if (zamd_inflate_segments_dev(e, g_gpu.d_in, s->in.size(), segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
 
+    tr.lap("count");
     // follow the chain of segments from the known block start
     std::vector<zamd_inflate_seg> chain;
     uint64_t produced = 0, end_bit = s->bit_off;
@@ -718,6 +753,7 @@ int decode_some(z_streamp strm, IState *s) {
         idx = lo;
     }
     if (chain.empty()) { s->tried = s->in.size(); return Z_OK; }
+    tr.lap("chain");
 
     if (produced) {
         if (grow(e, &g_gpu.d_out, &g_gpu.out_cap, produced + 64) != Z_OK) return Z_MEM_ERROR;
@@ -731,12 +767,14 @@ int decode_some(z_streamp strm, IState *s) {
             return Z_MEM_ERROR;
         for (const zamd_inflate_seg &g : chain)
             if (g.status >= 3) return ibad(strm, s, zamd_inflate_message(g.status));
+        tr.lap("place");
         if (s->wrap) {
             uint32_t v = s->check;
             int rc = s->gzip ? zamd_crc32_dev(e, v, g_gpu.d_out, produced, &v) : zamd_adler32_dev(e, v, g_gpu.d_out, produced, &v);
             if (rc != 0) return Z_MEM_ERROR;
             strm->adler = s->check = v;
         }
+        tr.lap("check");
         const uint8_t *got;
         if (s->out.size() == s->out_pos && strm->avail_out >= produced) {
             // nothing pending and room enough: straight into the caller's buffer
@@ -749,6 +787,7 @@ int decode_some(z_streamp strm, IState *s) {
             if (zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
             got = s->out.data() + at;
         }
+        tr.lap("download");
         s->total += produced;
         if (produced >= HIST) s->hist.assign(got + produced - HIST, got + produced);
         else {
@@ -766,6 +805,7 @@ int decode_some(z_streamp strm, IState *s) {
     s->cands.swap(keep);
     s->scanned = s->scanned > drop ? s->scanned - drop : 0;
     s->tried = 0;
+    tr.lap("tidy"); tr.done("inflate round");
     return Z_OK;
 }
 
