@@ -662,31 +662,40 @@ void idrain(z_streamp strm, IState *s) {
     if (s->out_pos == s->out.size()) { s->out.clear(); s->out_pos = 0; }
 }
 
-// One decode attempt over the buffered input.  Returns Z_OK (with or without
-// progress), Z_DATA_ERROR (msg set) or Z_MEM_ERROR.
-int decode_some(z_streamp strm, IState *s) {
-    if (s->in.size() * 8ull <= s->bit_off) return Z_OK;
+// One decode attempt over the buffered input, or, with `ext`, over the caller's own input buffer
+// (nothing is buffered then: what the attempt consumes is taken off next_in, the rest stays with the
+// caller).  Returns Z_OK (with or without progress), NO_PROGRESS (ext only: not one whole block in
+// there), Z_DATA_ERROR (msg set) or Z_MEM_ERROR.
+const int NO_PROGRESS = 100;
+int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t ext_n = 0) {
+    const bool view = ext != nullptr;
+    const uint8_t *const ip = view ? ext : s->in.data();
+    const size_t in_n = view ? ext_n : s->in.size();
+    std::vector<uint64_t> view_cands; size_t view_scanned = 0;
+    std::vector<uint64_t> &cands = view ? view_cands : s->cands;
+    size_t &scanned = view ? view_scanned : s->scanned;
+    if (in_n * 8ull <= s->bit_off) return view ? NO_PROGRESS : Z_OK;
     Trace tr;
     std::lock_guard<std::mutex> lk(g_gpu.mu);
     zamd_engine *e = engine_locked();
     if (!e) return Z_MEM_ERROR;
-    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, s->in.size() + 64) != Z_OK) return Z_MEM_ERROR;
-    if (zamd_dev_upload(e, g_gpu.d_in, s->in.data(), s->in.size()) != 0) return Z_MEM_ERROR;
+    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, in_n + 64) != Z_OK) return Z_MEM_ERROR;
+    if (zamd_dev_upload(e, g_gpu.d_in, ip, in_n) != 0) return Z_MEM_ERROR;
     tr.lap("upload");
     // sync-marker candidates: independent starting points for parallel wavefronts.  The bytes that are
     // new since the last attempt are searched on the GPU (a marker may straddle the old end).
     {
-        const uint64_t from = s->scanned < 3 ? 0 : s->scanned - 3;
+        const uint64_t from = scanned < 3 ? 0 : scanned - 3;
         std::vector<uint64_t> found(1u << 18);
         uint32_t cnt = 0;
-        if (zamd_find_sync_dev(e, g_gpu.d_in, from, s->in.size(), found.data(), (uint32_t)found.size(), &cnt) != 0) return Z_MEM_ERROR;
+        if (zamd_find_sync_dev(e, g_gpu.d_in, from, in_n, found.data(), (uint32_t)found.size(), &cnt) != 0) return Z_MEM_ERROR;
         if (cnt <= found.size()) {
             found.resize(cnt);
             std::sort(found.begin(), found.end());
         } else {                                        // more markers than the list holds: search on the host
             found.clear();
             static const uint8_t pat[4] = {0, 0, 0xff, 0xff};
-            const uint8_t *base = s->in.data(), *end = base + s->in.size();
+            const uint8_t *base = ip, *end = base + in_n;
             for (const uint8_t *q = base + from; q + 4 <= end;) {
                 const uint8_t *hit = (const uint8_t *)memmem(q, (size_t)(end - q), pat, 4);
                 if (!hit) break;
@@ -694,12 +703,12 @@ int decode_some(z_streamp strm, IState *s) {
                 q = hit + 1;
             }
         }
-        for (uint64_t c : found) if (s->cands.empty() || s->cands.back() < c) s->cands.push_back(c);
-        s->scanned = s->in.size();
+        for (uint64_t c : found) if (cands.empty() || cands.back() < c) cands.push_back(c);
+        scanned = in_n;
     }
     tr.lap("scan");
     std::vector<zamd_inflate_seg> segs;
-    const uint64_t end_bits = s->in.size() * 8ull;
+    const uint64_t end_bits = in_n * 8ull;
     // A candidate is a guess: what starts there may be the middle of a stored block, so its
     // wavefront gets a bounded amount of input and output (a real segment that is longer is
     // continued from where it stopped, as the known start of the next attempt).
@@ -711,9 +720,9 @@ int decode_some(z_streamp strm, IState *s) {
         segs.push_back(g);
     };
     add(s->bit_off, (uint32_t)s->hist.size(), false);
-    for (uint64_t c : s->cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST, true);
+    for (uint64_t c : cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST, true);
 
-    if (zamd_inflate_segments_dev(e, g_gpu.d_in, s->in.size(), segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
+    if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
 
     tr.lap("count");
     // follow the chain of segments from the known block start
@@ -726,7 +735,7 @@ int decode_some(z_streamp strm, IState *s) {
         if (g.out_len > s->out_batch && g.out_len > 0 && chain.empty()) {
             // one segment larger than the output batch: take a whole-block prefix of it
             zamd_inflate_seg one = g; one.out_cap = s->out_batch; one.status = 0;
-            if (zamd_inflate_segments_dev(e, g_gpu.d_in, s->in.size(), &one, 1, nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
+            if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, &one, 1, nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
             if (one.out_len == 0) { strm->msg = "deflate block too large for the GPU engine"; s->mode = IM_MEM; return Z_MEM_ERROR; }
             g = one; g.status = 3;
         }
@@ -752,7 +761,7 @@ int decode_some(z_streamp strm, IState *s) {
         if (lo >= segs.size() || segs[lo].in_bit != nb) break;
         idx = lo;
     }
-    if (chain.empty()) { s->tried = s->in.size(); return Z_OK; }
+    if (chain.empty()) { if (view) return NO_PROGRESS; s->tried = in_n; return Z_OK; }
     tr.lap("chain");
 
     if (produced) {
@@ -763,7 +772,7 @@ int decode_some(z_streamp strm, IState *s) {
             d_head = (uint8_t *)g_gpu.d_off;
             if (zamd_dev_upload(e, d_head + (HIST - s->hist.size()), s->hist.data(), s->hist.size()) != 0) return Z_MEM_ERROR;
         }
-        if (zamd_inflate_segments_dev(e, g_gpu.d_in, s->in.size(), chain.data(), chain.size(), d_head, g_gpu.d_out, produced) != 0)
+        if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, chain.data(), chain.size(), d_head, g_gpu.d_out, produced) != 0)
             return Z_MEM_ERROR;
         for (const zamd_inflate_seg &g : chain)
             if (g.status >= 3) return ibad(strm, s, zamd_inflate_message(g.status));
@@ -799,11 +808,14 @@ int decode_some(z_streamp strm, IState *s) {
     size_t drop = (size_t)(end_bit >> 3);
     if (final_block) { drop = (size_t)((end_bit + 7) >> 3); s->bit_off = 0; s->last = true; s->mode = IM_TRAILER; }
     else s->bit_off = (uint32_t)(end_bit & 7);
-    s->in.erase(s->in.begin(), s->in.begin() + drop);
-    std::vector<uint64_t> keep;
-    for (uint64_t c : s->cands) if (c > drop) keep.push_back(c - drop);
-    s->cands.swap(keep);
-    s->scanned = s->scanned > drop ? s->scanned - drop : 0;
+    if (view) { strm->next_in += drop; strm->avail_in -= (uInt)drop; strm->total_in += drop; }
+    else {
+        s->in.erase(s->in.begin(), s->in.begin() + drop);
+        std::vector<uint64_t> keep;
+        for (uint64_t c : cands) if (c > drop) keep.push_back(c - drop);
+        cands.swap(keep);
+        scanned = scanned > drop ? scanned - drop : 0;
+    }
     s->tried = 0;
     tr.lap("tidy"); tr.done("inflate round");
     return Z_OK;
@@ -943,6 +955,15 @@ int inflate(z_streamp strm, int flush) {
                 for (unsigned i = 0; i < nb; i++) s->in.push_back((uint8_t)(v >> (8 * i)));
                 s->bit_off = off; s->prime_bits = 0; s->prime_hold = 0;
             }
+            bool tried_all = false;
+            if (s->in.empty() && strm->avail_in >= (1u << 20)) {
+                // a large input is decoded where it lies; what a round does not use stays with the caller
+                const size_t n = strm->avail_in < (512u << 20) ? strm->avail_in : (512u << 20);
+                int rc = decode_some(strm, s, strm->next_in, n);
+                if (rc == Z_MEM_ERROR) { s->mode = IM_MEM; return Z_MEM_ERROR; }
+                if (rc != NO_PROGRESS) continue;
+                tried_all = n == strm->avail_in;            // not one whole block in there: buffer it and wait for more
+            }
             const size_t before = s->in.size();
             uint64_t room = (512ull << 20) > before ? (512ull << 20) - before : 0;
             uint64_t take = strm->avail_in < room ? strm->avail_in : room;
@@ -950,6 +971,7 @@ int inflate(z_streamp strm, int flush) {
                 s->in.insert(s->in.end(), strm->next_in, strm->next_in + take);
                 strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take;
             }
+            if (tried_all) s->tried = s->in.size();
             if (s->in.size() == s->tried) break;             // nothing new since the last fruitless attempt
             int rc = decode_some(strm, s);
             if (rc == Z_MEM_ERROR) { s->mode = IM_MEM; return Z_MEM_ERROR; }
