@@ -1085,7 +1085,10 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     uint64_t bc = e->ws_budget / (uint64_t)NS / per;
     if (bc < 1) bc = 1;
     if (bc > total_chunks) bc = total_chunks;
-    if (total_chunks > bc && total_chunks < (uint64_t)NS * bc) bc = (total_chunks + NS - 1) / NS;
+    /* fewer batches than streams: cut the work into one batch per stream so that the serial stages of one
+     * batch (k_hop, k_plan) run beside the parallel stages of another; not worth it for a handful of chunks */
+    static const uint64_t min_split = getenv("ZAMD_MIN_SPLIT") ? strtoull(getenv("ZAMD_MIN_SPLIT"), nullptr, 10) : 64;
+    if (total_chunks >= min_split && total_chunks < (uint64_t)NS * bc) bc = (total_chunks + NS - 1) / NS;
     if (bc > 0x7fffffu) bc = 0x7fffffu;
     const uint32_t batch = (uint32_t)bc;
     const uint32_t nbatches = (uint32_t)((total_chunks + batch - 1) / batch);
