@@ -137,7 +137,7 @@ def main():
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
             per_byte = [v["hbm_bytes_per_input_byte"] for k, v in prof["kernels"].items() if k.startswith("k_match")][0]
-            traffic = round(per_byte * (n / match_launches) / 1e9, 3)
+            traffic = round(per_byte * (n / match_launches) / 1e9, 3) if dominant == "match" else None    # no counter pass for k_fast
         except Exception:
             pass
         roofline = {"bound": "hbm", "kernel": "k_match" if dominant == "match" else "k_fast", "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",

@@ -1132,7 +1132,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         }
         /* k_match's records reproduce neither a nice length below the lazy limit nor a quarter budget of zero
          * (which wraps in the reference): those searches follow the parse (k_spec) */
-        const bool dense = P.parser == ZC_PARSE_RLE || !(e->spec_match || P.nice < P.lazy || P.chain < 4);
+        const bool dense = P.parser == ZC_PARSE_RLE || (P.parser == ZC_PARSE_SLOW && !(e->spec_match || P.nice < P.lazy || P.chain < 4));
         if (P.parser == ZC_PARSE_SLOW && !dense) {
             tm_begin(e, s, 1, &slot);
             HIPCHK(hipMemsetAsync(w.hop, 0, (uint64_t)J.nchunks * chunk_size * 4u, s));
