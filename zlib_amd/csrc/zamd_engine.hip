@@ -326,12 +326,6 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 kk -= wm;                                         /* count the candidate */
                 const int32_t dn = dist + d;
                 const int32_t go = (dn - lim) & kk & nohit & wm; /* negative iff the walk continues */
-                const int32_t fin = nohit & wm & ~go;             /* negative iff the walk ends here */
-                if (fin < 0) {
-                    uint32_t k = (uint32_t)(kk + (int32_t)max_chain);
-                    uint32_t rq = qb == 0 ? 0u : (k > qb ? qrec : full_now);
-                    rec[pout] = make_uint2(full_now, rq);
-                }
                 dist = go < 0 ? dn : dist;
                 c = go < 0 ? c - (uint32_t)d : c;
                 parked |= hit;
@@ -341,6 +335,13 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         }
         cur = c;
         parked >>= 31;
+        /* a walk that ended without a parked candidate leaves its counters frozen (a lane that is not
+         * walking counts nothing): its record is written here, outside the hot loop */
+        if ((walking & ~wm & ~parked) < 0) {
+            uint32_t k = (uint32_t)(kk + (int32_t)max_chain);
+            uint32_t rq = qb == 0 ? 0u : (k > qb ? qrec : full_now);
+            rec[pout] = make_uint2(full_now, rq);
+        }
         walking = wm | parked;                /* parked walks are still owned by the lane */
     }
 }
