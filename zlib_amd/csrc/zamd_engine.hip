@@ -306,7 +306,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         const uint32_t peek_off = (best - 2u) - la0;
         const uint16_t *link = s_pd - la0;
         uint32_t c = cur;                     /* candidate */
-        int32_t dist = (int32_t)(p - cur);
+        const int32_t plim = (int32_t)p - lim;       /* the next candidate c' is in reach while plim - c' < 0 */
         int32_t wm = walking;
 #pragma unroll 1
         for (int it = 0; it < 32; it++) {
@@ -324,9 +324,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
                 const int32_t hit = (int32_t)(x - 1u) & wm;      /* negative iff walking and matched */
                 kk -= wm;                                         /* count the candidate */
-                const int32_t dn = dist + d;
-                const int32_t go = (dn - lim) & kk & nohit & wm; /* negative iff the walk continues */
-                dist = go < 0 ? dn : dist;
+                const int32_t go = ((plim - (int32_t)c) + d) & kk & nohit & wm;   /* negative iff the walk continues */
                 c = go < 0 ? c - (uint32_t)d : c;
                 parked |= hit;
                 wm = go >> 31;
