@@ -309,9 +309,9 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         const int32_t plim = (int32_t)p - lim;       /* the next candidate c' is in reach while plim - c' < 0 */
         int32_t wm = walking;
 #pragma unroll 1
-        for (int it = 0; it < 32; it++) {
+        for (int it = 0; it < 8; it++) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < 8; u++) {
                 uint32_t v;
                 if (UNAL) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
                 else {
