@@ -308,6 +308,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         uint32_t c = cur;                     /* candidate */
         const int32_t plim = (int32_t)p - lim;       /* the next candidate c' is in reach while plim - c' < 0 */
         int32_t wm = walking;
+        uint32_t xlast = 1u;
 #pragma unroll 1
         for (int it = 0; it < 8; it++) {
 #pragma unroll
@@ -322,17 +323,18 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 const int32_t d = (int32_t)link[c];
                 const uint32_t x = (v & 0x00ffffffu) ^ scan3;
                 const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
-                const int32_t hit = (int32_t)(x - 1u) & wm;      /* negative iff walking and matched */
+                xlast = x;
                 kk -= wm;                                         /* count the candidate */
                 const int32_t go = ((plim - (int32_t)c) + d) & kk & nohit & wm;   /* negative iff the walk continues */
                 c = go < 0 ? c - (uint32_t)d : c;
-                parked |= hit;
                 wm = go >> 31;
             }
             if (__popcll(__ballot(wm == 0)) >= THRESH) break;
         }
         cur = c;
-        parked >>= 31;
+        /* a walk that stopped in this round stands on the candidate that stopped it and has looked at it
+         * again at every step since: it is parked if that candidate passed the peek */
+        parked = xlast == 0u ? (walking & ~wm) : 0;
         /* a walk that ended without a parked candidate leaves its counters frozen (a lane that is not
          * walking counts nothing): its record is written here, outside the hot loop */
         if ((walking & ~wm & ~parked) < 0) {
