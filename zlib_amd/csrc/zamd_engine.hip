@@ -318,7 +318,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 else {
                     const uint32_t ac = c + peek_off;
                     const uint32_t wi = ac >> 2;
-                    v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], ac & 3u);
+                    v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], ac);   /* the instruction uses bits 1:0 of the shift operand */
                 }
                 const int32_t d = (int32_t)link[c];
                 const uint32_t x = (v & 0x00ffffffu) ^ scan3;
