@@ -166,3 +166,26 @@ def test_results_do_not_depend_on_stale_device_memory(engine):
             blob = comp.compress(data) + comp.flush()
             res, out = engine.inflate_segments(blob, [_one_segment(engine, blob, out_cap=n, mode=zlib_amd.INF_EXACT)], out_bytes=max(n, 16))
             assert res[0]["status"] == 1 and out[:n] == data
+
+
+def test_sync_marker_search_on_the_gpu(engine):
+    """zamd_find_sync_dev: every 00 00 FF FF of a buffer, also overlapping ones and those at the very ends."""
+    import re
+    import random
+    rnd = random.Random(7)
+    buf = bytearray(rnd.getrandbits(8) for _ in range(300000))
+    marks = [0, 4, 17, 1000, 65530, 65536, 131071, len(buf) - 4]
+    for m in marks:
+        buf[m:m + 4] = b"\x00\x00\xff\xff"
+    buf[200000:200006] = b"\x00\x00\x00\xff\xff\xff"
+    data = bytes(buf)
+    want = [m.start() + 4 for m in re.finditer(b"(?=\x00\x00\xff\xff)", data)]
+    assert set(m + 4 for m in marks) <= set(want) and 200005 in want
+    assert engine.find_sync(data) == want
+    assert engine.find_sync(data, start=65534) == [w for w in want if w - 4 >= 65534]
+    assert engine.find_sync(data[:3]) == [] and engine.find_sync(b"\x00\x00\xff\xff") == [4]
+    # the chunk boundaries of an engine stream are among them
+    src = O.corpus(5 * 65536 + 99, 4, 201)
+    stream, offs = engine.deflate_chunks(src, level=6, chunk_size=65536)
+    found = set(engine.find_sync(stream))
+    assert all(o in found for o in offs[1:-1])

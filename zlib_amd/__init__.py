@@ -316,6 +316,21 @@ class Engine:
             if d_head is not None:
                 d_head.free()
 
+    def find_sync(self, stream, start: int = 0, cap: int = 1 << 16):
+        """zamd_find_sync_dev on host bytes: sorted offsets just behind every 00 00 FF FF at or after `start`."""
+        n = len(stream)
+        d = self.alloc(max(n, 16))
+        try:
+            d.upload(stream)
+            lst = (C.c_uint64 * cap)()
+            cnt = C.c_uint32(0)
+            _chk(self.lib.zamd_find_sync_dev(self.handle, d.ptr, start, n, lst, cap, C.byref(cnt)), "zamd_find_sync_dev")
+            if cnt.value > cap:
+                raise ZamdError(-5, "zamd_find_sync_dev", "more markers than the list holds", -1)
+            return sorted(lst[:cnt.value])
+        finally:
+            d.free()
+
     def inflate_segments(self, stream, segs, *, out_bytes: int = 0, head_window=None):
         """zamd_inflate_segments_dev on host bytes.  segs: list of dicts with the input fields of InflateSeg.
         Returns (list of result dicts, output bytes or None when out_bytes == 0)."""
