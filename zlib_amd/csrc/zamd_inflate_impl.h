@@ -496,16 +496,32 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
                 zi_span(B, sb, lane, L.lut_l, L.lut_d, tl, wd);
                 bool restart = false;
                 for (;;) {
-                    /* the hot loop: nothing but ordinary tokens */
+                    /* the hot part: nothing but ordinary tokens.  The scalar loop only follows the token
+                     * lengths and notes where tokens start; their words then move to the parking lanes
+                     * k, k+1, ... all at once (a forward lane permute: each starting lane sends its word
+                     * to the slot of its rank among the starting lanes) */
                     uint32_t t = 0;
                     if (sp < 64) {
+                        unsigned long long M = 0;
+                        uint32_t s2 = sp;
                         do {
-                            t = __builtin_amdgcn_readlane(tl, sp);
-                            const uint32_t w = __builtin_amdgcn_readlane(wd, sp);
+                            t = __builtin_amdgcn_readlane(tl, s2);
                             if (t >= 256u) break;
-                            mysym = zi_writelane(mysym, w, k);
-                            sp += t; k++;
-                        } while ((sp | k) < 64u);       /* both below 64 */
+                            M |= 1ull << s2;
+                            s2 += t;
+                        } while (s2 < 64u);
+                        const uint32_t c = (uint32_t)__popcll(M);
+                        if (c) {
+                            if (k + c > 64u) { B.bitpos = sb + sp; if (!flush()) { bad = true; break; } }   /* makes room: k = 0 */
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(M >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)M, 0u));
+                            const bool starts = (M >> lane) & 1ull;
+                            /* lanes that start no token send to a slot nobody reads */
+                            const uint32_t spare = k + c < 64u ? k + c : 0u;
+                            const uint32_t to = starts ? k + rank : spare;
+                            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_permute((int)(to << 2), (int)wd);
+                            if (lane - k < c) mysym = got;
+                            k += c; sp = s2;
+                        }
                     }
                     if (k == 64) { B.bitpos = sb + sp; if (!flush()) { bad = true; break; } continue; }
                     if (sp >= 64) break;
