@@ -16,4 +16,5 @@ d_in.upload(data)
 total = eng.deflate_dev(d_in.ptr, n, d_out.ptr, cap, level=level)
 names = ["chain", "match", "parse", "plan", "layout", "emit", "call"]
 t = {nm: eng.timing_ms(i)[0] for i, nm in enumerate(names)}
+t["match4"] = eng.timing_ms(10)[0]
 print("kind %d ratio %.3f fallback hops %d  " % (kind, n / total, int(eng.timing_ms(9)[0])) + "  ".join("%s %.1f" % (k, v) for k, v in t.items()), flush=True)

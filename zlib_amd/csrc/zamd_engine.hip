@@ -40,6 +40,7 @@ struct ZkJob {
     uint32_t prime_bits, prime_val;  /* deflatePrime bits in front of the call's first chunk */
     ZcParams P;
     uint16_t *pdist; uint64_t pdist_base, pdist_len;
+    uint16_t *l4, *f3d; uint8_t *sk, *f3s;   /* four-byte chains (k_link4), indexed like pdist */
     uint2 *rec; uint64_t rec_base;
     uint32_t *sym;
     uint32_t *hop; uint32_t *arr; uint32_t *nhop;
@@ -156,6 +157,46 @@ struct LdsPd {
     __device__ uint32_t operator()(uint32_t a) const { uint32_t v = pd[a - a0]; return v == ZK_PD_NONE ? 0u : v; }
 };
 
+/* Input bytes of a-coordinates a0 .. a0 + nbytes - 1 of a chunk into LDS (zero outside the input). */
+__device__ inline void zk_load_window(const ZkJob &J, const ZcChunkGeom &g, int64_t a0, uint32_t *s_win, uint32_t nbytes, uint32_t tid)
+{
+    for (uint32_t v = tid; v < nbytes / 16; v += ZK_MATCH_THREADS) {
+        int64_t a = a0 + 16 * (int64_t)v;
+        int64_t abs = (int64_t)g.dstart + a;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (a >= 0 && (uint64_t)abs + 16 <= J.n) q = *(const uint4 *)(J.in + abs);
+        else if (a + 16 > 0 && abs < (int64_t)J.n) {
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 16; k++) {
+                int64_t ak = a + k, absk = abs + k;
+                if (ak >= 0 && absk < (int64_t)J.n) t[k >> 2] |= (uint32_t)J.in[absk] << (8 * (k & 3));
+            }
+            q = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        ((uint4 *)s_win)[v] = q;
+    }
+}
+/* Chain links of a-coordinates a0 .. a0 + count - 1 into LDS; "none" (0) is stored as 0xffff so that adding it to a
+ * distance always exceeds MAX_DIST. */
+__device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64_t a0, uint16_t *s_pd, uint32_t count, uint32_t tid)
+{
+    for (uint32_t v = tid; v < count / 8; v += ZK_MATCH_THREADS) {
+        int64_t a = a0 + 8 * (int64_t)v;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (a >= 0) {
+            uint64_t idx = g.dstart + (uint64_t)a - J.pdist_base;
+            if (idx + 8 <= J.pdist_len) q = *(const uint4 *)(J.pdist + idx);
+        }
+        uint32_t t[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((t[k] & 0xffffu) == 0) t[k] |= 0xffffu;
+            if ((t[k] >> 16) == 0) t[k] |= 0xffff0000u;
+        }
+        ((uint4 *)s_pd)[v] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+}
+
 template <bool UNAL, int THRESH>
 __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t tiles_per_chunk, int rle)
 {
@@ -171,40 +212,8 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     const uint32_t t0 = g.dict_len + tile * ZK_TILE;
     const uint32_t tlen = (E - t0) < ZK_TILE ? (E - t0) : ZK_TILE;
     const int64_t a0 = (int64_t)t0 - (int64_t)ZK_HALO;      /* a-coordinate of LDS byte 0 */
-    /* window bytes */
-    for (uint32_t v = tid; v < ZK_WIN_BYTES / 16; v += ZK_MATCH_THREADS) {
-        int64_t a = a0 + 16 * (int64_t)v;
-        int64_t abs = (int64_t)g.dstart + a;
-        uint4 q = make_uint4(0, 0, 0, 0);
-        if (a >= 0 && (uint64_t)abs + 16 <= J.n) q = *(const uint4 *)(J.in + abs);
-        else if (a + 16 > 0 && abs < (int64_t)J.n) {
-            uint32_t t[4] = {0, 0, 0, 0};
-            for (int k = 0; k < 16; k++) {
-                int64_t ak = a + k, absk = abs + k;
-                if (ak >= 0 && absk < (int64_t)J.n) t[k >> 2] |= (uint32_t)J.in[absk] << (8 * (k & 3));
-            }
-            q = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-        ((uint4 *)s_win)[v] = q;
-    }
-    if (!rle) {
-        /* chain links; "none" (0) is stored as 0xffff so that adding it to a distance always exceeds MAX_DIST */
-        for (uint32_t v = tid; v < (ZK_HALO + ZK_TILE) / 8; v += ZK_MATCH_THREADS) {
-            int64_t a = a0 + 8 * (int64_t)v;
-            uint4 q = make_uint4(0, 0, 0, 0);
-            if (a >= 0) {
-                uint64_t idx = g.dstart + (uint64_t)a - J.pdist_base;
-                if (idx + 8 <= J.pdist_len) q = *(const uint4 *)(J.pdist + idx);
-            }
-            uint32_t t[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if ((t[k] & 0xffffu) == 0) t[k] |= 0xffffu;
-                if ((t[k] >> 16) == 0) t[k] |= 0xffff0000u;
-            }
-            ((uint4 *)s_pd)[v] = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-    }
+    zk_load_window(J, g, a0, s_win, ZK_WIN_BYTES, tid);
+    if (!rle) zk_load_links(J, g, a0, s_pd, ZK_HALO + ZK_TILE, tid);
     if (tid == 0) s_next = 0;
     __syncthreads();
     LdsWin win; win.w = s_win; win.a0 = (uint32_t)a0;
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     }
 }
 
+#include "zamd_match4_impl.h"
 #include "zamd_spec_impl.h"
 
 /* ------------------------------------------------------------------ k_parse
@@ -875,7 +885,7 @@ __global__ __launch_bounds__(256) void k_checksum(const uint8_t *in, uint64_t n,
 
 struct ZeWorkspace {
     uint32_t cap_chunks = 0, chunk_size = 0, max_blocks = 0;
-    uint16_t *pdist = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr; uint32_t *hop = nullptr; uint32_t *nhop = nullptr;
+    uint16_t *pdist = nullptr, *l4 = nullptr, *f3d = nullptr; uint8_t *sk = nullptr, *f3s = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr; uint32_t *hop = nullptr; uint32_t *nhop = nullptr;
     ZcBlock *blk = nullptr; ZcBlockTab *tab = nullptr;
     uint32_t *nblk = nullptr, *nsym = nullptr; uint64_t *chunk_bytes = nullptr, *sync_bit = nullptr;
     uint64_t pdist_len = 0;
@@ -892,6 +902,7 @@ struct zamd_engine {
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
     int spec_match;                 /* follow the parse (k_spec) instead of searching every position (k_match) */
+    int chain4_match;               /* search along four-byte chains (k_link4 + k_match4) where the chain budget allows */
     uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
     int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
     uint64_t ws_budget;
@@ -909,7 +920,7 @@ struct zamd_engine {
 
 static void ws_free(ZeWorkspace &w)
 {
-    hipFree(w.pdist); hipFree(w.rec); hipFree(w.sym); hipFree(w.hop); hipFree(w.nhop); hipFree(w.blk); hipFree(w.tab);
+    hipFree(w.pdist); hipFree(w.l4); hipFree(w.f3d); hipFree(w.sk); hipFree(w.f3s); hipFree(w.rec); hipFree(w.sym); hipFree(w.hop); hipFree(w.nhop); hipFree(w.blk); hipFree(w.tab);
     hipFree(w.nblk); hipFree(w.nsym); hipFree(w.chunk_bytes); hipFree(w.sync_bit); hipFree(w.fhead);
     w = ZeWorkspace();
 }
@@ -958,6 +969,7 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     for (int i = 0; i < ZE_STREAMS; i++) e->ws[i] = ZeWorkspace();
     e->nstreams = 4;                 /* one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4) */
     e->spec_match = getenv("ZAMD_MATCH_SPEC") ? 1 : 0;
+    e->chain4_match = getenv("ZAMD_MATCH_CHAIN4") ? 1 : 0;
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->device = device;
     e->ws_budget = workspace_bytes ? workspace_bytes : (48ull << 30);
@@ -1119,6 +1131,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         J.finish = finish; J.P = P; J.prime_bits = prime_bits; J.prime_val = prime_val;
         ZcChunkGeom g0 = zc_geom(J.n, chunk_size, J.chunk0, finish, J.head);
         J.pdist = w.pdist; J.pdist_base = g0.dstart; J.pdist_len = w.pdist_len;
+        J.l4 = w.l4; J.f3d = w.f3d; J.sk = w.sk; J.f3s = w.f3s;
         J.rec = w.rec; J.rec_base = head_dict_len + J.chunk0 * chunk_size;
         J.sym = w.sym; J.hop = w.hop; J.nhop = w.nhop; J.arr = (uint32_t *)w.rec; J.blk = w.blk; J.tab = w.tab; J.nblk = w.nblk; J.nsym = w.nsym;
         J.chunk_bytes = w.chunk_bytes; J.sync_bit = w.sync_bit;
@@ -1150,7 +1163,22 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                 static int mv = getenv("ZAMD_MV") ? atoi(getenv("ZAMD_MV")) : 0;
                 int rle = P.parser == ZC_PARSE_RLE ? 1 : 0;
                 dim3 grid(J.nchunks * tiles), blk(ZK_MATCH_THREADS);
-                if (mv == 1) hipLaunchKernelGGL((k_match<true, 20>), grid, blk, 0, s, J, tiles, rle);
+                /* optional: budgets that fit the eight-bit step counts of the four-byte chains can search along those */
+                if (!rle && e->chain4_match && P.chain <= ZK4_MAX_CHAIN && P.nice >= 4) {
+                    if (!w.l4) {          /* 6 bytes per position more, only for engines that use this search */
+                        HIPCHK(hipMalloc((void **)&w.l4, w.pdist_len * 2));
+                        HIPCHK(hipMalloc((void **)&w.f3d, w.pdist_len * 2));
+                        HIPCHK(hipMalloc((void **)&w.sk, w.pdist_len));
+                        HIPCHK(hipMalloc((void **)&w.f3s, w.pdist_len));
+                        J.l4 = w.l4; J.f3d = w.f3d; J.sk = w.sk; J.f3s = w.f3s;
+                    }
+                    const uint32_t ltiles = (ZC_WSIZE + chunk_size + ZK_TILE - 1) / ZK_TILE, mtiles = (chunk_size + ZK4_TILE - 1) / ZK4_TILE;
+                    hipLaunchKernelGGL((k_link4<32>), dim3(J.nchunks * ltiles), blk, 0, s, J, ltiles);
+                    tm_end(e, s, slot);
+                    tm_begin(e, s, 10, &slot);
+                    hipLaunchKernelGGL((k_match4<32>), dim3(J.nchunks * mtiles), blk, 0, s, J, mtiles);
+                }
+                else if (mv == 1) hipLaunchKernelGGL((k_match<true, 20>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 2) hipLaunchKernelGGL((k_match<false, 12>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 3) hipLaunchKernelGGL((k_match<false, 44>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 4) hipLaunchKernelGGL((k_match<false, 20>), grid, blk, 0, s, J, tiles, rle);
