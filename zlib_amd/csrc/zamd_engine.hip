@@ -251,11 +251,25 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     for (;;) {
         /* ---- full comparisons of parked candidates (zc_match_extend, then zc_match_advance) */
         if (parked < 0) {
-            uint32_t len = 0;
-            while (len < cap) {
-                uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
-                if (x) { len += zc_ctz32(x) >> 3; break; }
-                len += 4;
+            /* the first 16 bytes of both strings in one LDS round trip (most comparisons end there), then 4 at a time */
+            uint32_t len, dnext;
+            {
+                const uint32_t oc = cur - la0, op = p - la0, ic = oc >> 2, ip = op >> 2;
+                dnext = pd(cur);                /* the link, fetched in the same round trip */
+                const uint32_t c0 = s_win[ic], c1 = s_win[ic + 1], c2 = s_win[ic + 2], c3 = s_win[ic + 3], c4 = s_win[ic + 4];
+                const uint32_t q0 = s_win[ip], q1 = s_win[ip + 1], q2 = s_win[ip + 2], q3 = s_win[ip + 3], q4 = s_win[ip + 4];
+                const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, oc) ^ __builtin_amdgcn_alignbyte(q1, q0, op);
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, oc) ^ __builtin_amdgcn_alignbyte(q2, q1, op);
+                const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, oc) ^ __builtin_amdgcn_alignbyte(q3, q2, op);
+                const uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, oc) ^ __builtin_amdgcn_alignbyte(q4, q3, op);
+                len = x0 ? zc_ctz32(x0) >> 3 : x1 ? 4u + (zc_ctz32(x1) >> 3) : x2 ? 8u + (zc_ctz32(x2) >> 3) : x3 ? 12u + (zc_ctz32(x3) >> 3) : 16u;
+            }
+            if (len == 16u) {
+                while (len < cap) {
+                    uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
+                    if (x) { len += zc_ctz32(x) >> 3; break; }
+                    len += 4;
+                }
             }
             if (len > cap) len = cap;
             bool fin = false;
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 else scan3 = win.load4(p + len - 2u) & 0x00ffffffu;
             }
             if (!fin) {
-                uint32_t d = pd(cur);
+                const uint32_t d = dnext;
                 if (kk >= 0 || d == 0 || d >= cur) fin = true;
                 else { cur -= d; fin = p - cur >= ZC_MAX_DIST; }
             }
