@@ -202,6 +202,23 @@ const char *gzerror(gzFile file, int *errnum);                                  
 void gzclearerr(gzFile file);                                                                       /* gzlib.c:549 */
 #define gzgetc(g) ((g)->have ? ((g)->have--, (g)->pos++, *((g)->next)++) : gzgetc(g))               /* zlib.h:1684-1686 */
 
+/* ---- chunk index: this library only, no counterpart in the reference (examples/zran.c:67-72 builds
+ * comparable access points by inflating a file once).  deflate() cuts its input into chunks that each end on a
+ * byte boundary; the index lists, per chunk in stream order, { compressed bytes, inflated bytes }. */
+int zamd_deflate_index(z_streamp strm, int enable);         /* after deflateInit/Reset, before the first input */
+int zamd_deflate_index_get(z_streamp strm, const unsigned **pairs, unsigned *n_chunks);
+                                                             /* after Z_STREAM_END, before deflateReset; Z_DATA_ERROR: the
+                                                                stream has no byte-aligned chunk grid (deflatePrime) */
+int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_chunks);
+                                                             /* after inflateInit/Reset: the index of the deflate data that
+                                                                follows; inflate() then places whole chunks in one pass.  A
+                                                                hint that does not fit the data is dropped, not trusted */
+/* The same index kept in a gzip file: gzopen(path, "wbI") (or ZAMD_GZ_INDEX=1) appends it as empty gzip members
+ * that every gzip reader skips; gzopen for reading finds and uses it (ZAMD_GZ_INDEX=0: ignores it). */
+typedef struct zamd_gz_index { unsigned long long member_offset; unsigned n_chunks; unsigned *pairs; } zamd_gz_index;
+int zamd_gz_index_load(int fd, zamd_gz_index *out);          /* 0 = found, -1 = the file carries no index */
+void zamd_gz_index_free(zamd_gz_index *ix);
+
 #define deflateInit(strm, level) deflateInit_((strm), (level), ZLIB_VERSION, (int)sizeof(z_stream))
 #define deflateInit2(strm, level, method, windowBits, memLevel, strategy) \
     deflateInit2_((strm), (level), (method), (windowBits), (memLevel), (strategy), ZLIB_VERSION, (int)sizeof(z_stream))

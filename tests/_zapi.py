@@ -34,6 +34,10 @@ class GzHeader(C.Structure):       # zlib.h:109-129
 _lib = None
 
 
+class GzIndex(C.Structure):
+    _fields_ = [("member_offset", C.c_ulonglong), ("n_chunks", C.c_uint), ("pairs", C.POINTER(C.c_uint))]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -103,6 +107,11 @@ def lib():
         l.gzerror.argtypes = [G, C.POINTER(C.c_int)]; l.gzerror.restype = C.c_char_p
         l.gzclearerr.argtypes = [G]; l.gzclearerr.restype = None
         l.gzprintf.restype = C.c_int
+        l.zamd_deflate_index.argtypes = [P, C.c_int]
+        l.zamd_deflate_index_get.argtypes = [P, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.c_uint)]
+        l.zamd_inflate_index_hint.argtypes = [P, C.POINTER(C.c_uint), C.c_uint]
+        l.zamd_gz_index_load.argtypes = [C.c_int, C.POINTER(GzIndex)]
+        l.zamd_gz_index_free.argtypes = [C.POINTER(GzIndex)]; l.zamd_gz_index_free.restype = None
         _lib = l
     return _lib
 
@@ -128,7 +137,7 @@ def uncompress(comp, cap):
     return rc, buf.raw[:n.value] if rc == 0 else b""
 
 
-def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out_step=65536, flushes=None, header=None):
+def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out_step=65536, flushes=None, header=None, index=None):
     """Feeds `data` through deflate() in in_step slices with out_step output space per call.
     flushes: {offset: flush} applied when the input cursor reaches offset.  Returns (rc_list_tail, bytes, strm)."""
     l = lib()
@@ -137,6 +146,8 @@ def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out
     assert rc == 0, rc
     if header is not None:
         assert l.deflateSetHeader(C.byref(s), C.byref(header)) == 0
+    if index is not None:                      # a list that receives (compressed bytes, inflated bytes) per chunk
+        assert l.zamd_deflate_index(C.byref(s), 1) == 0
     src = C.create_string_buffer(bytes(data), max(len(data), 1))
     out = bytearray()
     obuf = C.create_string_buffer(out_step)
@@ -178,11 +189,16 @@ def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out
                 assert rc == Z_OK, rc
             break
     totals = (s.total_in, s.total_out, s.adler)
+    if index is not None:
+        pairs, cnt = C.POINTER(C.c_uint)(), C.c_uint(0)
+        rc = l.zamd_deflate_index_get(C.byref(s), C.byref(pairs), C.byref(cnt))
+        index.append(rc)
+        index.extend((pairs[2 * i], pairs[2 * i + 1]) for i in range(cnt.value))
     assert l.deflateEnd(C.byref(s)) == 0
     return bytes(out), totals
 
 
-def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUSH, header=None, dictionary=None):
+def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUSH, header=None, dictionary=None, hint=None):
     """Feeds `comp` through inflate().  Returns (rc, bytes, msg, unused_input, totals)."""
     l = lib()
     s = ZStream()
@@ -190,6 +206,9 @@ def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUS
     assert rc == 0, rc
     if header is not None:
         assert l.inflateGetHeader(C.byref(s), C.byref(header)) == 0
+    if hint is not None:                       # [(compressed bytes, inflated bytes), ...] of the deflate data
+        flat = (C.c_uint * (2 * len(hint)))(*[v for pair in hint for v in pair])
+        assert l.zamd_inflate_index_hint(C.byref(s), flat, len(hint)) == 0
     src = C.create_string_buffer(bytes(comp), max(len(comp), 1))
     obuf = C.create_string_buffer(out_step)
     out = bytearray()

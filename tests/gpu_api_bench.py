@@ -19,22 +19,28 @@ back = C.create_string_buffer(n)
 for it in range(2):
     s = Z.ZStream()
     assert l.deflateInit2_(C.byref(s), level, 8, 31, 8, 0, Z.VERSION, Z.SZ) == 0
+    assert l.zamd_deflate_index(C.byref(s), 1) == 0
     s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), n, C.addressof(out), cap
     t0 = time.time()
     rc = l.deflate(C.byref(s), Z.Z_FINISH)
     dt = time.time() - t0
     assert rc == Z.Z_STREAM_END, rc
     total = s.total_out
+    pairs, cnt = C.POINTER(C.c_uint)(), C.c_uint(0)
+    assert l.zamd_deflate_index_get(C.byref(s), C.byref(pairs), C.byref(cnt)) == 0
+    index = (C.c_uint * (2 * cnt.value))(*pairs[:2 * cnt.value])
     l.deflateEnd(C.byref(s))
     print("deflate(): %d -> %d in %.1f ms = %.2f GB/s (host buffers, gzip wrapper)" % (n, total, dt * 1e3, n / dt / 1e9), flush=True)
-for it in range(2):
+for it in range(4):
     s = Z.ZStream()
     assert l.inflateInit2_(C.byref(s), 47, Z.VERSION, Z.SZ) == 0
+    if it >= 2:
+        assert l.zamd_inflate_index_hint(C.byref(s), index, len(index) // 2) == 0
     s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(out), total, C.addressof(back), n
     t0 = time.time()
     rc = l.inflate(C.byref(s), Z.Z_FINISH)
     dt = time.time() - t0
     assert rc == Z.Z_STREAM_END, (rc, s.msg)
     l.inflateEnd(C.byref(s))
-    print("inflate(): %.1f ms = %.2f GB/s of output (host buffers)" % (dt * 1e3, n / dt / 1e9), flush=True)
+    print("inflate()%s: %.1f ms = %.2f GB/s of output (host buffers)" % (" with the chunk index" if it >= 2 else "", dt * 1e3, n / dt / 1e9), flush=True)
 print("round trip", "OK" if back.raw == bytes(data) else "MISMATCH")

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     names = set()
     for fn in os.listdir(os.path.join(ROOT, "include")):
-        if not fn.endswith(".h"):
+        if not fn.endswith(".h") or fn == "zamd_zlib.h":       # that header is libzamd_z.so's, checked below
             continue
         text = open(os.path.join(ROOT, "include", fn)).read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)

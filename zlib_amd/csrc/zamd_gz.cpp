@@ -8,6 +8,13 @@
  * round trip, so the buffers default to 32 MiB (the reference: 8 KiB, gzguts.h:147)
  * — gzbuffer() and ZAMD_GZ_BUF_MIB change that — and reads hand inflate() the whole
  * input buffer at once.
+ *
+ * Chunk index (no counterpart in the reference's gz layer; examples/zran.c:67-72 keeps such access points in
+ * memory): a file written with an 'I' in the mode string, or with ZAMD_GZ_INDEX=1 in the environment, is
+ * followed by empty gzip members whose FEXTRA field lists, per chunk of the deflate data, its compressed and
+ * its inflated length.  Any gzip reader skips them (they inflate to nothing); this reader finds them from the
+ * end of the file and hands them to inflate(), which then places whole chunks in one pass.  Layout: see
+ * zamd_gz_index_load below and the integration notes.
  */
 #include "../../include/zamd_zlib.h"
 
@@ -24,6 +31,9 @@
 #include <new>
 #include <string>
 #include <vector>
+
+extern "C" int zamd_gz_index_load(int fd, zamd_gz_index *out);
+extern "C" void zamd_gz_index_free(zamd_gz_index *ix);
 
 namespace {
 
@@ -43,6 +53,11 @@ struct GzFile {
     int eof, past;
     /* writing */
     int level, strategy;
+    int want_index, members;    /* chunk index asked for; gzip members finished so far */
+    uint64_t base, produced, member_at;   /* file offset at open, deflate() output so far, where the open member started */
+    std::vector<unsigned> index; uint64_t index_member;
+    /* reading */
+    std::vector<unsigned> ridx; uint64_t ridx_member; int have_ridx;
     /* seek request */
     z_off64_t skip; int seek;
     /* error */
@@ -91,6 +106,8 @@ gzFile open_file(const char *path, int fd, const char *mode)      /* gz_open, gz
     s->size = 0; s->want = default_want();
     s->mode = GZ_NONE; s->level = Z_DEFAULT_COMPRESSION; s->strategy = Z_DEFAULT_STRATEGY; s->direct = 0;
     s->err = Z_OK; s->how = LOOK; s->eof = s->past = 0; s->seek = 0; s->skip = 0; s->start = 0;
+    s->want_index = 0; s->members = 0; s->base = s->produced = s->member_at = s->index_member = 0; s->have_ridx = 0; s->ridx_member = 0;
+    { const char *v = getenv("ZAMD_GZ_INDEX"); if (v && *v && *v != '0') s->want_index = 1; }
     int cloexec = 0, exclusive = 0;
     for (; *mode; mode++) {
         if (*mode >= '0' && *mode <= '9') { s->level = *mode - '0'; continue; }
@@ -106,6 +123,7 @@ gzFile open_file(const char *path, int fd, const char *mode)      /* gz_open, gz
         case 'R': s->strategy = Z_RLE; break;
         case 'F': s->strategy = Z_FIXED; break;
         case 'T': s->direct = 1; break;
+        case 'I': s->want_index = 1; break;            /* this library only: append a chunk index */
         default: break;                                /* 'b' and anything unknown */
         }
     }
@@ -123,10 +141,24 @@ gzFile open_file(const char *path, int fd, const char *mode)      /* gz_open, gz
 #endif
     s->fd = fd > -1 ? fd : open(path, oflag, 0666);
     if (s->fd == -1) { delete s; return NULL; }
+    const bool append = s->mode == GZ_APPEND;
     if (s->mode == GZ_APPEND) s->mode = GZ_WRITE;
     if (s->mode == GZ_READ) {
         s->start = lseek(s->fd, 0, SEEK_CUR);
         if (s->start == -1) s->start = 0;
+        const char *v = getenv("ZAMD_GZ_INDEX");
+        if (!(v && *v == '0')) {
+            zamd_gz_index ix;
+            if (zamd_gz_index_load(s->fd, &ix) == 0) {
+                s->ridx.assign(ix.pairs, ix.pairs + 2 * (size_t)ix.n_chunks);
+                s->ridx_member = ix.member_offset; s->have_ridx = 1;
+                zamd_gz_index_free(&ix);
+            }
+            lseek(s->fd, s->start, SEEK_SET);
+        }
+    } else {
+        z_off64_t at = lseek(s->fd, 0, append ? SEEK_END : SEEK_CUR);
+        s->base = at == -1 ? 0 : (uint64_t)at;
     }
     reset(s);
     return (gzFile)s;
@@ -181,6 +213,11 @@ int look(GzFile *s)                                     /* gz_look, gzread.c:86-
     }
     if (z.avail_in > 1 && z.next_in[0] == 31 && z.next_in[1] == 139) {
         inflateReset(&z);
+        if (s->have_ridx) {
+            z_off64_t at = lseek(s->fd, 0, SEEK_CUR);
+            if (at != -1 && (uint64_t)at - z.avail_in == s->ridx_member)
+                zamd_inflate_index_hint(&z, s->ridx.data(), (unsigned)(s->ridx.size() / 2));
+        }
         s->how = GZIP; s->direct = 0;
         return 0;
     }
@@ -266,6 +303,7 @@ int winit(GzFile *s)                                    /* gz_init, gzwrite.c:15
             set_error(s, Z_MEM_ERROR, "out of memory");
             return -1;
         }
+        if (s->want_index) zamd_deflate_index(&z, 1);
     }
     s->size = s->want;
     if (!s->direct) { z.avail_out = s->size; z.next_out = s->out.data(); s->x.next = z.next_out; }
@@ -305,8 +343,19 @@ int comp(GzFile *s, int flush)                          /* gz_comp, gzwrite.c:74
         ret = deflate(&z, flush);
         if (ret == Z_STREAM_ERROR) { set_error(s, Z_STREAM_ERROR, "internal error: deflate stream corrupt"); return -1; }
         made -= z.avail_out;
+        s->produced += made;
     } while (made);
-    if (flush == Z_FINISH) deflateReset(&z);            /* the next write starts a new member */
+    if (flush == Z_FINISH) {
+        if (s->want_index) {                            /* the index of the member that just ended, before the reset forgets it */
+            const unsigned *pairs; unsigned n;
+            s->index.clear();
+            if (s->members == 0 && zamd_deflate_index_get(&z, &pairs, &n) == Z_OK) { s->index.assign(pairs, pairs + 2 * (size_t)n); s->index_member = s->base + s->member_at; }
+        }
+        s->members++;
+        s->member_at = s->produced;
+        deflateReset(&z);                               /* the next write starts a new member */
+        if (s->want_index) zamd_deflate_index(&z, 1);
+    }
     return 0;
 }
 
@@ -326,9 +375,89 @@ int zeros(GzFile *s, z_off64_t len)                     /* gz_zero, gzwrite.c:13
     return 0;
 }
 
+/* ------------------------------------------------------------------ chunk index
+ * One index member = a gzip member with no data: 1f 8b 08 04, mtime 0, xfl 0, os 3, XLEN, one FEXTRA subfield
+ * 'Z' 'I', then the empty final block 03 00, crc 0, isize 0.  Subfield payload (little endian):
+ *   u8 version (1), u8 flags (bit 0: last index member), u16 0, u32 n,
+ *   u64 offset in the file of the gzip member that is described, u64 number of the first chunk listed here,
+ *   n x { u32 compressed bytes, u32 inflated bytes }   chunks of that member's deflate data, in order,
+ *   and in the last index member only: u64 offset in the file of the first index member, "ZAMI".
+ * So the last 22 bytes of an indexed file are: that offset, "ZAMI", 03 00, eight zero bytes. */
+const unsigned IDX_PER_MEMBER = 8000;
+void put16(std::vector<unsigned char> &v, unsigned x) { v.push_back((unsigned char)x); v.push_back((unsigned char)(x >> 8)); }
+void put32(std::vector<unsigned char> &v, uint32_t x) { put16(v, x & 0xffffu); put16(v, x >> 16); }
+void put64(std::vector<unsigned char> &v, uint64_t x) { put32(v, (uint32_t)x); put32(v, (uint32_t)(x >> 32)); }
+
+int write_index(GzFile *s)
+{
+    const size_t nch = s->index.size() / 2;
+    const uint64_t first_member = s->base + s->produced;
+    std::vector<unsigned char> o;
+    for (size_t c0 = 0; c0 < nch; c0 += IDX_PER_MEMBER) {
+        const size_t n = nch - c0 < IDX_PER_MEMBER ? nch - c0 : IDX_PER_MEMBER;
+        const bool last = c0 + n == nch;
+        const unsigned payload = 24u + 8u * (unsigned)n + (last ? 12u : 0u);
+        static const unsigned char head[10] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 3};
+        o.insert(o.end(), head, head + 10);
+        put16(o, payload + 4u);
+        o.push_back('Z'); o.push_back('I'); put16(o, payload);
+        o.push_back(1); o.push_back(last ? 1 : 0); put16(o, 0); put32(o, (uint32_t)n);
+        put64(o, s->index_member); put64(o, c0);
+        for (size_t c = c0; c < c0 + n; c++) { put32(o, s->index[2 * c]); put32(o, s->index[2 * c + 1]); }
+        if (last) { put64(o, first_member); o.push_back('Z'); o.push_back('A'); o.push_back('M'); o.push_back('I'); }
+        o.push_back(3); o.push_back(0);
+        for (int k = 0; k < 8; k++) o.push_back(0);
+    }
+    return write_all(s, o.data(), o.size());
+}
+
 }  // namespace
 
 extern "C" {
+
+/* Reads the chunk index at the end of the file behind fd (which must be seekable; its position is left
+ * anywhere).  0 = found: out->pairs holds n_chunks x { compressed bytes, inflated bytes } (free with
+ * zamd_gz_index_free), out->member_offset the file offset of the gzip member they describe.  -1 = no index. */
+int zamd_gz_index_load(int fd, zamd_gz_index *out)
+{
+    if (out == NULL) return -1;
+    memset(out, 0, sizeof *out);
+    const off_t end = lseek(fd, 0, SEEK_END);
+    if (end == (off_t)-1 || end < 22 + 10 + 2 + 4 + 24) return -1;
+    unsigned char tail[22];
+    if (pread(fd, tail, 22, end - 22) != 22) return -1;
+    static const unsigned char fin[10] = {3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (memcmp(tail + 8, "ZAMI", 4) != 0 || memcmp(tail + 12, fin, 10) != 0) return -1;
+    auto rd = [](const unsigned char *p, int n) { uint64_t v = 0; for (int i = n - 1; i >= 0; i--) v = (v << 8) | p[i]; return v; };
+    uint64_t at = rd(tail, 8);
+    if (at >= (uint64_t)end) return -1;
+    std::vector<unsigned> pairs;
+    uint64_t member = 0;
+    for (;;) {
+        unsigned char h[16 + 24];
+        if (at + sizeof h > (uint64_t)end || pread(fd, h, sizeof h, (off_t)at) != (ssize_t)sizeof h) return -1;
+        if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || h[3] != 4 || h[12] != 'Z' || h[13] != 'I' || h[16] != 1) return -1;
+        const unsigned xlen = (unsigned)rd(h + 10, 2), plen = (unsigned)rd(h + 14, 2);
+        const unsigned flags = h[17];
+        const uint64_t n = rd(h + 20, 4), first = rd(h + 32, 8);
+        if (plen + 4u != xlen || plen != 24u + 8u * n + ((flags & 1) ? 12u : 0u) || first != pairs.size() / 2) return -1;
+        if (pairs.empty()) member = rd(h + 24, 8); else if (member != rd(h + 24, 8)) return -1;
+        std::vector<unsigned char> body(8 * n);
+        if (n && pread(fd, body.data(), body.size(), (off_t)(at + sizeof h)) != (ssize_t)body.size()) return -1;
+        for (uint64_t i = 0; i < 2 * n; i++) pairs.push_back((unsigned)rd(body.data() + 4 * i, 4));
+        at += 12 + xlen + 10;
+        if (flags & 1) break;
+    }
+    if (at != (uint64_t)end) return -1;
+    out->pairs = (unsigned *)malloc(pairs.size() * sizeof(unsigned) + 1);
+    if (out->pairs == NULL) return -1;
+    if (!pairs.empty()) memcpy(out->pairs, pairs.data(), pairs.size() * sizeof(unsigned));
+    out->n_chunks = (unsigned)(pairs.size() / 2);
+    out->member_offset = member;
+    return 0;
+}
+
+void zamd_gz_index_free(zamd_gz_index *ix) { if (ix) { free(ix->pairs); ix->pairs = NULL; ix->n_chunks = 0; } }
 
 gzFile gzopen(const char *path, const char *mode) { return open_file(path, -1, mode); }       /* gzlib.c:268 */
 gzFile gzopen64(const char *path, const char *mode) { return open_file(path, -1, mode); }     /* gzlib.c:276 */
@@ -654,6 +783,7 @@ int gzclose_w(gzFile file)                                                      
     int ret = Z_OK;
     if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) ret = s->err; }
     if (comp(s, Z_FINISH) == -1) ret = s->err;
+    if (ret == Z_OK && s->want_index && !s->direct && s->members == 1 && !s->index.empty() && write_index(s) == -1) ret = s->err;
     if (s->size && !s->direct) (void)deflateEnd(&s->strm);
     if (close(s->fd) == -1) ret = Z_ERRNO;
     delete s;

@@ -124,6 +124,8 @@ struct DState {
     std::vector<uint8_t> in;           // input accepted from the caller, not yet compressed
     std::vector<uint8_t> out;          // produced output not yet handed to the caller
     size_t out_pos;
+    bool index_on, index_ok;           // chunk index wanted (zamd_deflate_index); still describes the whole stream
+    std::vector<uint32_t> index;       // per chunk since the last reset: compressed bytes, inflated bytes
 };
 
 inline DState *dstate(z_streamp strm) {
@@ -216,9 +218,25 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     if (rc == 0) {
         if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
         if (rc == 0 && s->prime_bits) { rc = zamd_engine_prime(e, (int)s->prime_bits, (int)s->prime_val); s->prime_bits = 0; s->prime_val = 0; }
+        const uint64_t nch = n ? (n + s->chunk_size - 1) / s->chunk_size : 1;
+        uint64_t *d_tab = nullptr;
+        if (rc == 0 && s->index_on && s->index_ok) {
+            if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, (nch + 1) * 8 > HIST ? (nch + 1) * 8 : HIST) != Z_OK) return Z_MEM_ERROR;
+            d_tab = g_gpu.d_off;
+        }
         if (rc == 0)
             rc = zamd_deflate_shard_dev(e, g_gpu.d_in + HIST, n, head, s->chunk_size, s->level, s->strategy,
-                                        s->mem_level, finish, g_gpu.d_out, bound, nullptr, &total);
+                                        s->mem_level, finish, g_gpu.d_out, bound, d_tab, &total);
+        if (rc == 0 && d_tab) {
+            // chunks end on byte boundaries (a sync marker or the final block), so byte counts describe them
+            std::vector<uint64_t> off(nch + 1);
+            rc = zamd_dev_download(e, off.data(), d_tab, (nch + 1) * 8);
+            for (uint64_t c = 0; rc == 0 && c < nch; c++) {
+                const uint64_t raw = n ? ((c + 1) * s->chunk_size <= n ? s->chunk_size : n - c * s->chunk_size) : 0;
+                s->index.push_back((uint32_t)(off[c + 1] - off[c]));
+                s->index.push_back((uint32_t)raw);
+            }
+        }
         if (s->tuned) zamd_engine_tune(e, 0, 0, 0, 0);      // the engine is shared by all streams
     }
     tr.lap("deflate");
@@ -340,6 +358,7 @@ int deflateResetKeep(z_streamp strm) {
     s->trailer_done = false;
     s->have_dict = false; s->dictid = 0;
     s->prime_bits = 0; s->prime_val = 0;
+    s->index.clear(); s->index_ok = true;
     return Z_OK;
 }
 
@@ -407,6 +426,7 @@ int deflatePrime(z_streamp strm, int bits, int value) {     // deflate.c:464-487
     uint32_t have = s->prime_bits + (uint32_t)bits;
     while (have >= 8) { s->out.push_back((uint8_t)hold); hold >>= 8; have -= 8; }
     s->prime_bits = have; s->prime_val = (uint32_t)hold;
+    s->index_ok = false;                   // inserted bits are not part of any chunk
     return Z_OK;
 }
 
@@ -534,6 +554,26 @@ int deflateCopy(z_streamp dest, z_streamp source) {
     return Z_OK;
 }
 
+// Chunk index of the stream being written (no counterpart in the reference; the access points of
+// examples/zran.c:67-72 serve the same end): one entry per chunk, in stream order.
+int zamd_deflate_index(z_streamp strm, int enable) {
+    DState *s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (s->since_reset != 0 || !s->in.empty()) return Z_STREAM_ERROR;     // before the first input only
+    s->index_on = enable != 0;
+    s->index.clear(); s->index_ok = true;
+    return Z_OK;
+}
+int zamd_deflate_index_get(z_streamp strm, const unsigned **pairs, unsigned *n_chunks) {
+    DState *s = dstate(strm);
+    if (!s || pairs == Z_NULL || n_chunks == Z_NULL) return Z_STREAM_ERROR;
+    *pairs = Z_NULL; *n_chunks = 0;
+    if (!s->index_on) return Z_STREAM_ERROR;
+    if (!s->index_ok) return Z_DATA_ERROR;
+    *pairs = s->index.data(); *n_chunks = (unsigned)(s->index.size() / 2);
+    return Z_OK;
+}
+
 // ------------------------------------------------------------------ inflate side
 }  // extern "C"
 
@@ -560,6 +600,7 @@ struct IState {
     uint32_t dictid;
     uint64_t out_batch;
     uint64_t prime_hold; unsigned prime_bits;   // inflatePrime bits waiting in front of the first input byte
+    std::vector<uint32_t> hints; size_t hint_pos;   // chunk index of the deflate data ahead (zamd_inflate_index_hint): compressed bytes, inflated bytes per chunk
 };
 
 inline IState *istate(z_streamp strm) {
@@ -666,7 +707,7 @@ void idrain(z_streamp strm, IState *s) {
 // (nothing is buffered then: what the attempt consumes is taken off next_in, the rest stays with the
 // caller).  Returns Z_OK (with or without progress), NO_PROGRESS (ext only: not one whole block in
 // there), Z_DATA_ERROR (msg set) or Z_MEM_ERROR.
-const int NO_PROGRESS = 100;
+const int NO_PROGRESS = 100, HINT_MISFIT = 101;
 int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t ext_n = 0) {
     const bool view = ext != nullptr;
     const uint8_t *const ip = view ? ext : s->in.data();
@@ -682,86 +723,116 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, in_n + 64) != Z_OK) return Z_MEM_ERROR;
     if (zamd_dev_upload(e, g_gpu.d_in, ip, in_n) != 0) return Z_MEM_ERROR;
     tr.lap("upload");
-    // sync-marker candidates: independent starting points for parallel wavefronts.  The bytes that are
-    // new since the last attempt are searched on the GPU (a marker may straddle the old end).
-    {
-        const uint64_t from = scanned < 3 ? 0 : scanned - 3;
-        std::vector<uint64_t> found(1u << 18);
-        uint32_t cnt = 0;
-        if (zamd_find_sync_dev(e, g_gpu.d_in, from, in_n, found.data(), (uint32_t)found.size(), &cnt) != 0) return Z_MEM_ERROR;
-        if (cnt <= found.size()) {
-            found.resize(cnt);
-            std::sort(found.begin(), found.end());
-        } else {                                        // more markers than the list holds: search on the host
-            found.clear();
-            static const uint8_t pat[4] = {0, 0, 0xff, 0xff};
-            const uint8_t *base = ip, *end = base + in_n;
-            for (const uint8_t *q = base + from; q + 4 <= end;) {
-                const uint8_t *hit = (const uint8_t *)memmem(q, (size_t)(end - q), pat, 4);
-                if (!hit) break;
-                found.push_back((uint64_t)(hit - base) + 4);
-                q = hit + 1;
-            }
-        }
-        for (uint64_t c : found) if (cands.empty() || cands.back() < c) cands.push_back(c);
-        scanned = in_n;
-    }
-    tr.lap("scan");
-    std::vector<zamd_inflate_seg> segs;
     const uint64_t end_bits = in_n * 8ull;
-    // A candidate is a guess: what starts there may be the middle of a stored block, so its
-    // wavefront gets a bounded amount of input and output (a real segment that is longer is
-    // continued from where it stopped, as the known start of the next attempt).
-    const uint64_t spec_bits = 96ull << 23, spec_out = 96ull << 20;
-    auto add = [&](uint64_t bit, uint32_t win, bool guess) {
-        zamd_inflate_seg g; memset(&g, 0, sizeof g);
-        g.in_bit = bit; g.in_end_bit = (guess && bit + spec_bits < end_bits) ? bit + spec_bits : end_bits;
-        g.out_off = 0; g.out_cap = guess ? spec_out : (~0ull >> 2); g.win_avail = win; g.mode = ZAMD_INF_SYNCSTOP;
-        segs.push_back(g);
-    };
-    add(s->bit_off, (uint32_t)s->hist.size(), false);
-    for (uint64_t c : cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST, true);
-
-    if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
-
-    tr.lap("count");
-    // follow the chain of segments from the known block start
     std::vector<zamd_inflate_seg> chain;
     uint64_t produced = 0, end_bit = s->bit_off;
     bool final_block = false;
-    size_t idx = 0;
-    for (;;) {
-        zamd_inflate_seg g = segs[idx];
-        if (g.out_len > s->out_batch && g.out_len > 0 && chain.empty()) {
-            // one segment larger than the output batch: take a whole-block prefix of it
-            zamd_inflate_seg one = g; one.out_cap = s->out_batch; one.status = 0;
-            if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, &one, 1, nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
-            if (one.out_len == 0) { strm->msg = "deflate block too large for the GPU engine"; s->mode = IM_MEM; return Z_MEM_ERROR; }
-            g = one; g.status = 3;
-        }
-        if ((produced + g.out_len > s->out_batch || chain.size() >= 8192) && !chain.empty()) break;
-        if (g.end_bit > g.in_bit || g.status == 1) {
+    // With a chunk index for the data ahead, the chunks that are complete in the input are placed directly:
+    // no marker search and no counting pass.  An index that turns out not to fit the data is dropped and
+    // the attempt starts over without it.
+    bool hinted = false;
+    size_t hints_used = 0;
+    if (s->hint_pos < s->hints.size() && s->bit_off == 0) {
+        uint64_t pos = 0;
+        for (size_t h = s->hint_pos; h + 1 < s->hints.size() && chain.size() < 8192; h += 2) {
+            const uint64_t clen = s->hints[h], raw = s->hints[h + 1];
+            if (raw == 0 || pos + clen > in_n || (produced + raw > s->out_batch && !chain.empty())) break;
+            zamd_inflate_seg g; memset(&g, 0, sizeof g);
+            g.in_bit = pos * 8; g.in_end_bit = (pos + clen) * 8; g.out_off = produced; g.out_cap = raw; g.out_len = raw;
             g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
-            g.out_off = produced; g.out_cap = g.out_len; g.in_end_bit = g.end_bit; g.mode = ZAMD_INF_EXACT;
+            g.mode = ZAMD_INF_EXACT;
             chain.push_back(g);
-            produced += g.out_len; end_bit = g.end_bit;
+            pos += clen; produced += raw; hints_used += 2;
         }
-        if (g.status >= 16) {
-            // valid blocks in front of the error are delivered first; the error (or, for a guess that hit
-            // its output bound, the rest of the segment) comes back on the next attempt
-            if (chain.empty()) return ibad(strm, s, zamd_inflate_message(g.status));
-            break;
+        hinted = !chain.empty();
+        if (hinted) end_bit = pos * 8;
+        else if (s->hints[s->hint_pos + 1] != 0 && s->hints[s->hint_pos + 1] <= s->out_batch) {
+            // the next chunk is not whole in the input yet: wait for the rest rather than leave the chunk grid
+            if (view) return NO_PROGRESS;
+            s->tried = in_n;
+            return Z_OK;
         }
-        if (g.status == 1) { final_block = true; break; }
-        if (g.status != 2) break;                            // input (or the output batch) ran out inside this segment
-        // stopped at a sync marker: the next segment is the candidate that starts there
-        uint64_t nb = g.end_bit;
-        size_t lo = idx + 1, hi = segs.size();
-        while (lo < hi) { size_t mid = (lo + hi) / 2; if (segs[mid].in_bit < nb) lo = mid + 1; else hi = mid; }
-        if (lo >= segs.size() || segs[lo].in_bit != nb) break;
-        idx = lo;
+        else { s->hints.clear(); s->hint_pos = 0; }         // an empty or oversized chunk: the general path takes over
+    }
+    if (!hinted) {
+        // sync-marker candidates: independent starting points for parallel wavefronts.  The bytes that are
+        // new since the last attempt are searched on the GPU (a marker may straddle the old end).
+        {
+            const uint64_t from = scanned < 3 ? 0 : scanned - 3;
+            std::vector<uint64_t> found(1u << 18);
+            uint32_t cnt = 0;
+            if (zamd_find_sync_dev(e, g_gpu.d_in, from, in_n, found.data(), (uint32_t)found.size(), &cnt) != 0) return Z_MEM_ERROR;
+            if (cnt <= found.size()) {
+                found.resize(cnt);
+                std::sort(found.begin(), found.end());
+            } else {                                        // more markers than the list holds: search on the host
+                found.clear();
+                static const uint8_t pat[4] = {0, 0, 0xff, 0xff};
+                const uint8_t *base = ip, *end = base + in_n;
+                for (const uint8_t *q = base + from; q + 4 <= end;) {
+                    const uint8_t *hit = (const uint8_t *)memmem(q, (size_t)(end - q), pat, 4);
+                    if (!hit) break;
+                    found.push_back((uint64_t)(hit - base) + 4);
+                    q = hit + 1;
+                }
+            }
+            for (uint64_t c : found) if (cands.empty() || cands.back() < c) cands.push_back(c);
+            scanned = in_n;
+        }
+        tr.lap("scan");
+        std::vector<zamd_inflate_seg> segs;
+        // A candidate is a guess: what starts there may be the middle of a stored block, so its
+        // wavefront gets a bounded amount of input and output (a real segment that is longer is
+        // continued from where it stopped, as the known start of the next attempt).
+        const uint64_t spec_bits = 96ull << 23, spec_out = 96ull << 20;
+        auto add = [&](uint64_t bit, uint32_t win, bool guess) {
+            zamd_inflate_seg g; memset(&g, 0, sizeof g);
+            g.in_bit = bit; g.in_end_bit = (guess && bit + spec_bits < end_bits) ? bit + spec_bits : end_bits;
+            g.out_off = 0; g.out_cap = guess ? spec_out : (~0ull >> 2); g.win_avail = win; g.mode = ZAMD_INF_SYNCSTOP;
+            segs.push_back(g);
+        };
+        add(s->bit_off, (uint32_t)s->hist.size(), false);
+        for (uint64_t c : cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST, true);
+
+        if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
+
+        tr.lap("count");
+        // follow the chain of segments from the known block start
+        size_t idx = 0;
+        for (;;) {
+            zamd_inflate_seg g = segs[idx];
+            if (g.out_len > s->out_batch && g.out_len > 0 && chain.empty()) {
+                // one segment larger than the output batch: take a whole-block prefix of it
+                zamd_inflate_seg one = g; one.out_cap = s->out_batch; one.status = 0;
+                if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, &one, 1, nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
+                if (one.out_len == 0) { strm->msg = "deflate block too large for the GPU engine"; s->mode = IM_MEM; return Z_MEM_ERROR; }
+                g = one; g.status = 3;
+            }
+            if ((produced + g.out_len > s->out_batch || chain.size() >= 8192) && !chain.empty()) break;
+            if (g.end_bit > g.in_bit || g.status == 1) {
+                g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
+                g.out_off = produced; g.out_cap = g.out_len; g.in_end_bit = g.end_bit; g.mode = ZAMD_INF_EXACT;
+                chain.push_back(g);
+                produced += g.out_len; end_bit = g.end_bit;
+            }
+            if (g.status >= 16) {
+                // valid blocks in front of the error are delivered first; the error (or, for a guess that hit
+                // its output bound, the rest of the segment) comes back on the next attempt
+                if (chain.empty()) return ibad(strm, s, zamd_inflate_message(g.status));
+                break;
+            }
+            if (g.status == 1) { final_block = true; break; }
+            if (g.status != 2) break;                            // input (or the output batch) ran out inside this segment
+            // stopped at a sync marker: the next segment is the candidate that starts there
+            uint64_t nb = g.end_bit;
+            size_t lo = idx + 1, hi = segs.size();
+            while (lo < hi) { size_t mid = (lo + hi) / 2; if (segs[mid].in_bit < nb) lo = mid + 1; else hi = mid; }
+            if (lo >= segs.size() || segs[lo].in_bit != nb) break;
+            idx = lo;
+        }
     }
     if (chain.empty()) { if (view) return NO_PROGRESS; s->tried = in_n; return Z_OK; }
+    if (!hinted) { s->hints.clear(); s->hint_pos = 0; }      // progress off the chunk grid: an index no longer applies
     tr.lap("chain");
 
     if (produced) {
@@ -775,7 +846,17 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, chain.data(), chain.size(), d_head, g_gpu.d_out, produced) != 0)
             return Z_MEM_ERROR;
         for (const zamd_inflate_seg &g : chain)
-            if (g.status >= 3) return ibad(strm, s, zamd_inflate_message(g.status));
+            if (g.status >= 3) {
+                if (hinted) { s->hints.clear(); s->hint_pos = 0; return HINT_MISFIT; }
+                return ibad(strm, s, zamd_inflate_message(g.status));
+            }
+        if (hinted) {
+            // the final block may only close the last chunk taken
+            for (size_t i = 0; i + 1 < chain.size(); i++)
+                if (chain[i].status == 1) { s->hints.clear(); s->hint_pos = 0; return HINT_MISFIT; }
+            final_block = chain.back().status == 1;
+            s->hint_pos += hints_used;
+        }
         tr.lap("place");
         if (s->wrap) {
             uint32_t v = s->check;
@@ -832,6 +913,7 @@ int istate_reset(z_streamp strm, IState *s, bool keep_window) {
     s->hdr.clear(); s->in.clear(); s->cands.clear(); s->out.clear();
     s->bit_off = 0; s->scanned = 0; s->tried = 0; s->out_pos = 0; s->check = 0; s->dictid = 0;
     s->prime_hold = 0; s->prime_bits = 0;
+    s->hints.clear(); s->hint_pos = 0;
     if (!keep_window) s->hist.clear();
     return Z_OK;
 }
@@ -995,6 +1077,18 @@ int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
     s->hist.insert(s->hist.end(), dictionary, dictionary + dictLength);
     if (s->hist.size() > HIST) s->hist.erase(s->hist.begin(), s->hist.end() - HIST);
     s->havedict = true;
+    return Z_OK;
+}
+
+// The chunk index of the deflate data that follows (entries as zamd_deflate_index_get hands them out):
+// inflate() then places whole chunks directly instead of searching for their boundaries.  A hint that
+// does not fit the data costs time, not correctness: it is dropped and the data decoded without it.
+int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_chunks) {
+    IState *s = istate(strm);
+    if (!s || (pairs == Z_NULL && n_chunks)) return Z_STREAM_ERROR;
+    if (s->mode != IM_HEAD && !(s->mode == IM_BODY && s->total == 0 && s->in.empty())) return Z_STREAM_ERROR;
+    s->hints.assign(pairs, pairs + 2 * (size_t)n_chunks);
+    s->hint_pos = 0;
     return Z_OK;
 }
 
