@@ -59,7 +59,7 @@ static int unpack(const char *name, unsigned char *buf)
 
 int main(int argc, char **argv)
 {
-    int decompress = 0, rc = 0;
+    int decompress = 0, rc = 0, want_index = 0;
     char mode[8] = "wb6";
     unsigned char *buf = (unsigned char *)malloc(PIECE);
     if (!buf) return 2;
@@ -71,9 +71,11 @@ int main(int argc, char **argv)
             else if (a[1] == 'f') strcpy(mode + 3, "f");
             else if (a[1] == 'h') strcpy(mode + 3, "h");
             else if (a[1] == 'r') strcpy(mode + 3, "R");
-            else { fprintf(stderr, "usage: zamd_gzip [-d] [-1..-9] [-f|-h|-r] file...\n"); return 2; }
+            else if (a[1] == 'i') want_index = 1;         /* append the chunk index (this library's gz layer only) */
+            else { fprintf(stderr, "usage: zamd_gzip [-d] [-1..-9] [-f|-h|-r] [-i] file...\n"); return 2; }
             continue;
         }
+        if (want_index && !strchr(mode, 'I')) strcat(mode, "I");
         rc |= decompress ? unpack(a, buf) : pack(a, mode, buf);
     }
     free(buf);
