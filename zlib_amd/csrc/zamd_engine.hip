@@ -325,12 +325,17 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         const uint32_t full_now = best >= 3u ? (best | (bdist << 16)) : 0u;   /* best is fixed while walking */
         const uint32_t pout = p - t0;
         const int32_t lim = (int32_t)(p < ZC_MAX_DIST ? p : ZC_MAX_DIST);      /* stop once the distance reaches this */
-        const uint8_t *peek = s_winb + (best - 2u) - la0;   /* + candidate a-coordinate = address of its bytes best-2.. */
+        /* the loop runs on ac = candidate + (best - 2) - la0, the LDS byte offset of the candidate's bytes best-2..,
+         * so that neither the peek address nor the link address nor the distance test needs an addition of its own */
+        const uint8_t *peek = s_winb;
         const uint32_t peek_off = (best - 2u) - la0;
-        const uint16_t *link = s_pd - la0;
-        uint32_t c = cur;                     /* candidate */
-        const int32_t plim = (int32_t)p - lim;       /* the next candidate c' is in reach while plim - c' < 0 */
+        const uint16_t *link = s_pd - (best - 2u);   /* link[ac] is the link of the candidate */
+        uint32_t c = cur + peek_off;
+        const int32_t plim = (int32_t)p - lim + (int32_t)peek_off;   /* the next candidate c' is in reach while plim - c' < 0 */
+        /* a walk that has stopped stays stopped without being told: it looks at the same candidate again (same peek,
+         * same link, same distance) and its count is frozen; lanes that are not walking get a count that says "budget spent" */
         int32_t wm = walking;
+        int32_t kc = kk & walking;
         uint32_t xlast = 1u;
 #pragma unroll 1
         for (int it = 0; it < 8; it++) {
@@ -339,22 +344,23 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 uint32_t v;
                 if (UNAL) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
                 else {
-                    const uint32_t ac = c + peek_off;
-                    const uint32_t wi = ac >> 2;
-                    v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], ac);   /* the instruction uses bits 1:0 of the shift operand */
+                    const uint32_t wi = c >> 2;
+                    v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], c);   /* the instruction uses bits 1:0 of the shift operand */
                 }
                 const int32_t d = (int32_t)link[c];
                 const uint32_t x = (v & 0x00ffffffu) ^ scan3;
                 const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
                 xlast = x;
-                kk -= wm;                                         /* count the candidate */
-                const int32_t go = ((plim - (int32_t)c) + d) & kk & nohit & wm;   /* negative iff the walk continues */
-                c = go < 0 ? c - (uint32_t)d : c;
+                kc -= wm;                                         /* count the candidate */
+                const int32_t go = ((plim - (int32_t)c) + d) & kc & nohit;   /* negative iff the walk continues */
                 wm = go >> 31;
+                c += (uint32_t)__mul24(d, wm);                    /* one multiply-add: c -= d where the walk continues */
+                asm("" : "+v"(c));                              /* keeps the compiler from deriving the next link address by a multiply of its own */
             }
             if (__popcll(__ballot(wm == 0)) >= THRESH) break;
         }
-        cur = c;
+        if (walking < 0) kk = kc;
+        cur = c - peek_off;
         /* a walk that stopped in this round stands on the candidate that stopped it and has looked at it
          * again at every step since: it is parked if that candidate passed the peek */
         parked = xlast == 0u ? (walking & ~wm) : 0;
