@@ -197,7 +197,9 @@ __device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64
     }
 }
 
-template <bool UNAL, int THRESH>
+/* MODE 0: the peek is three bytes (best-2..best) out of two aligned LDS dwords; 1: one unaligned dword;
+ * 2: the peek is the one aligned dword that holds the candidate's byte best-1, masked to the bytes 0..best */
+template <int MODE, int THRESH>
 __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t tiles_per_chunk, int rle)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_lds[ZK_LDS_BYTES / 4];
@@ -244,6 +246,14 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     const uint32_t la0 = (uint32_t)a0;
     const uint8_t *s_winb = (const uint8_t *)s_win;
     uint32_t p = t0, cur = t0, best = 2, bdist = 0, qrec = 0, scan3 = 0, cap = 0, nice = 0;
+    uint32_t sc1 = 0, msk0 = 0;               /* MODE 2: scan3:sc1 = the bytes best-4..best+3 of the string at p, masked; msk0 = mask of the first four */
+    auto set_scan = [&](uint32_t b) {
+        if (MODE == 2) {
+            msk0 = b >= 4u ? 0xffffffffu : 0xffffffffu << (8u * (4u - b));
+            scan3 = win.load4(p + b - 4u) & msk0;
+            sc1 = win.load4(p + b) & 0xffu;
+        } else scan3 = win.load4(p + b - 2u) & 0x00ffffffu;
+    };
     int32_t kk = 0;                           /* candidates examined minus max_chain: negative while budget remains */
     int32_t walking = 0, parked = 0;          /* sign masks: -1 / 0 */
     uint32_t wcur = 0, wend = 0;              /* this wave's ticket of unclaimed tile positions */
@@ -279,7 +289,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 best = len; bdist = p - cur;
                 if (k <= qb) qrec = best | (bdist << 16);   /* best of the first max_chain/4 candidates */
                 if (len >= nice) fin = true;
-                else scan3 = win.load4(p + len - 2u) & 0x00ffffffu;
+                else set_scan(len);
             }
             if (!fin) {
                 const uint32_t d = dnext;
@@ -315,6 +325,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 if (zc_match_init(win, pd, t0 + idx, E, g.corner, nice_match, st)) {
                     p = st.p; cur = st.cur; kk = -(int32_t)max_chain; best = 2; bdist = 0; qrec = 0;
                     scan3 = st.scan3; cap = st.cap; nice = st.nice;
+                    if (MODE == 2) set_scan(2u);
                     walking = -1;
                 } else rec[idx] = make_uint2(0u, 0u);
             }
@@ -337,12 +348,44 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         int32_t wm = walking;
         int32_t kc = kk & walking;
         uint32_t xlast = 1u;
+        if (MODE == 2) {
+            /* the loop variable is n = ~(LDS byte offset of the candidate's byte best-1): its low bits are the byte
+             * shift that lines the scan bytes up with the aligned dword, and distance test and link address are one
+             * instruction each from it */
+            uint32_t n = ~((cur + best - 1u) - la0);
+            const int32_t K = (int32_t)ZK_PD_OFF - 2 * (int32_t)best;
+            const int32_t Kt = (int32_t)p - lim - (int32_t)la0 + (int32_t)best;
+            uint32_t wpos = (uint32_t)walking >> 31;
+            int32_t zlast = 0;
+#pragma unroll 1
+            for (int it = 0; it < 8; it++) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t W = *(const uint32_t *)(s_winb + ~(n | 3u));
+                    uint32_t la;
+                    asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(la) : "v"(n), "v"(K));      /* K - 2n, written out: the compiler makes two instructions of it */
+                    const int32_t d = (int32_t)*(const uint16_t *)(s_winb + la);
+                    const uint32_t sw = __builtin_amdgcn_alignbyte(sc1, scan3, n), mk = __builtin_amdgcn_alignbyte(0xffu, msk0, n);
+                    /* -1 when every byte that counts is equal, otherwise not negative */
+                    const int32_t z = (int32_t)__builtin_amdgcn_sad_u8((W ^ sw) & mk, 0u, 0xffffffffu);
+                    zlast = z;
+                    kc += (int32_t)wpos;
+                    const int32_t go = ((int32_t)n + d + Kt) & kc & ~z;
+                    wpos = (uint32_t)go >> 31;
+                    asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(n) : "v"(d), "v"(wpos));   /* n += d where the walk continues */
+                }
+                if (__popcll(__ballot(wpos == 0u)) >= THRESH) break;
+            }
+            wm = -(int32_t)wpos;
+            xlast = zlast < 0 ? 0u : 1u;
+            c = (la0 - n - best) + peek_off;
+        } else {
 #pragma unroll 1
         for (int it = 0; it < 8; it++) {
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 uint32_t v;
-                if (UNAL) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
+                if (MODE == 1) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
                 else {
                     const uint32_t wi = c >> 2;
                     v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], c);   /* the instruction uses bits 1:0 of the shift operand */
@@ -358,6 +401,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 asm("" : "+v"(c));                              /* keeps the compiler from deriving the next link address by a multiply of its own */
             }
             if (__popcll(__ballot(wm == 0)) >= THRESH) break;
+        }
         }
         if (walking < 0) kk = kc;
         cur = c - peek_off;
@@ -1198,11 +1242,16 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                     tm_begin(e, s, 10, &slot);
                     hipLaunchKernelGGL((k_match4<32>), dim3(J.nchunks * mtiles), blk, 0, s, J, mtiles);
                 }
-                else if (mv == 1) hipLaunchKernelGGL((k_match<true, 20>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 2) hipLaunchKernelGGL((k_match<false, 12>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 3) hipLaunchKernelGGL((k_match<false, 44>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 4) hipLaunchKernelGGL((k_match<false, 20>), grid, blk, 0, s, J, tiles, rle);
-                else hipLaunchKernelGGL((k_match<false, 32>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 1) hipLaunchKernelGGL((k_match<1, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 2) hipLaunchKernelGGL((k_match<0, 12>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 3) hipLaunchKernelGGL((k_match<0, 44>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 4) hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 5) hipLaunchKernelGGL((k_match<2, 32>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 6) hipLaunchKernelGGL((k_match<2, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 7) hipLaunchKernelGGL((k_match<0, 16>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 8) hipLaunchKernelGGL((k_match<0, 24>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 9) hipLaunchKernelGGL((k_match<0, 32>), grid, blk, 0, s, J, tiles, rle);
+                else hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
             }
             tm_end(e, s, slot);
         }
