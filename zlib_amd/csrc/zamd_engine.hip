@@ -419,6 +419,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     }
 }
 
+#include "zamd_match2_impl.h"
 #include "zamd_match4_impl.h"
 #include "zamd_spec_impl.h"
 
@@ -1248,6 +1249,9 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                 else if (mv == 4) hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 5) hipLaunchKernelGGL((k_match<2, 32>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 6) hipLaunchKernelGGL((k_match<2, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 10 && !rle) hipLaunchKernelGGL((k_match2<20>), grid, blk, 0, s, J, tiles);
+                else if (mv == 11 && !rle) hipLaunchKernelGGL((k_match2<32>), grid, blk, 0, s, J, tiles);
+                else if (mv == 12 && !rle) hipLaunchKernelGGL((k_match2<12>), grid, blk, 0, s, J, tiles);
                 else if (mv == 7) hipLaunchKernelGGL((k_match<0, 16>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 8) hipLaunchKernelGGL((k_match<0, 24>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 9) hipLaunchKernelGGL((k_match<0, 32>), grid, blk, 0, s, J, tiles, rle);
