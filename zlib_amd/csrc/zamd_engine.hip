@@ -420,6 +420,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
 }
 
 #include "zamd_match2_impl.h"
+#include "zamd_match8_impl.h"
 #include "zamd_match4_impl.h"
 #include "zamd_spec_impl.h"
 
@@ -1249,6 +1250,13 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                 else if (mv == 4) hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 5) hipLaunchKernelGGL((k_match<2, 32>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 6) hipLaunchKernelGGL((k_match<2, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv >= 13 && mv <= 15 && !rle) {
+                    const uint32_t t8 = (chunk_size + ZK8_TILE - 1) / ZK8_TILE;
+                    dim3 grid8(J.nchunks * t8);
+                    if (mv == 13) hipLaunchKernelGGL((k_match8<20>), grid8, blk, 0, s, J, t8);
+                    else if (mv == 14) hipLaunchKernelGGL((k_match8<12>), grid8, blk, 0, s, J, t8);
+                    else hipLaunchKernelGGL((k_match8<28>), grid8, blk, 0, s, J, t8);
+                }
                 else if (mv == 10 && !rle) hipLaunchKernelGGL((k_match2<20>), grid, blk, 0, s, J, tiles);
                 else if (mv == 11 && !rle) hipLaunchKernelGGL((k_match2<32>), grid, blk, 0, s, J, tiles);
                 else if (mv == 12 && !rle) hipLaunchKernelGGL((k_match2<12>), grid, blk, 0, s, J, tiles);
