@@ -9,7 +9,7 @@
  * (zc_parse_fast) is wave-uniform; what keeps it off the memory latency:
  *   - a lone wavefront issues at most one instruction every four cycles, so what
  *     counts is how many chunks a CU parses at once: the LDS holds only prev[] of
- *     the newest 8 Ki positions (16 KiB: ten wavefronts per CU);
+ *     the newest 2 Ki positions (4 KiB: a CU's 32 wavefront slots are all usable);
  *     older links, head[] and the input bytes are read from global memory;
  *   - head[] is never on the critical path: the hashes
  *     of the next 128 positions are computed by the lanes and their head entries
@@ -20,7 +20,12 @@
  *     once, one per lane.
  */
 
-#define ZF_NEAR 8192u       /* links of the newest ZF_NEAR positions are kept in LDS (16 KiB: ten wavefronts per CU) */
+/* Links of the newest ZF_NEAR positions are kept in LDS.  4 KiB per wavefront lets a CU hold its 32 wavefronts, and
+ * chunks in flight are what this kernel lives on (measured on 8 GiB of text at level 1: 16 KiB 5.3 GB/s, 8 KiB 7.3,
+ * 4 KiB 8.0, 2 KiB 7.8 — the links further back come from global memory). */
+#ifndef ZF_NEAR
+#define ZF_NEAR 2048u
+#endif
 
 struct ZkFastCtx {
     const uint8_t *b;             /* a-coordinate 0 */
