@@ -8,7 +8,7 @@
  *   - the compressed bytes are held 2 x 256 B at a time in two VGPRs (one dword
  *     per lane) and picked out with v_readlane, so the bit reader makes no
  *     memory access per symbol;
- *   - Huffman tables are per-wave LDS images: a 2^10 (literal/length) or 2^8
+ *   - Huffman tables are per-wave LDS images: a 2^9 (literal/length) or 2^8
  *     (distance) first-level table of u16 {symbol, length}; longer codes fall
  *     back to the canonical first-code search;
  *   - decoded symbols are parked one per lane; every 64 symbols the wave scans
@@ -24,11 +24,20 @@
  * length sets); error numbers map to the reference's message strings.
  */
 
-#define ZI_ROOT_L 10
+/* Table and stage sizes set the LDS per wavefront and with it the wavefronts a CU holds: 10 root bits and a stage of
+ * 1 024 elements (9 KB, 17 wavefronts) decode 8 GiB at 52 GB/s, 9 bits and 512 elements (6 KB, 27 wavefronts) at 56;
+ * 8 root bits send too many symbols to the search for longer codes (41 GB/s). */
+#ifndef ZI_ROOT_L
+#define ZI_ROOT_L 9
+#endif
+#ifndef ZI_ROOT_D
 #define ZI_ROOT_D 8
+#endif
 #define ZI_ROOT_C 7
 #define ZI_MARK   256u       /* first marker value: byte 0 of the preceding 32 KiB */
-#define ZI_STAGE  1024u      /* elements of the per-wave output stage (>= 258) */
+#ifndef ZI_STAGE
+#define ZI_STAGE  512u       /* elements of the per-wave output stage (>= 258) */
+#endif
 #define ZI_EMPTY  0xffffu    /* stage element not produced yet (no byte or marker has this value) */
 __constant__ uint8_t zi_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   /* inflate.c:608-609 */
 
