@@ -25,7 +25,24 @@ def collect(d, counter):
     return {k: (v[0], len(v[1])) for k, v in acc.items()}
 
 
+def all_counters(dirs):
+    """--counters DIR...: every counter of every pass, summed over the dispatches of each kernel"""
+    acc = {}
+    for d in dirs:
+        for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(fn)):
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                acc.setdefault(name, {}).setdefault(row["Counter_Name"], 0.0)
+                acc[name][row["Counter_Name"]] += float(row["Counter_Value"])
+    for k in sorted(acc):
+        print(k)
+        for c in sorted(acc[k]):
+            print("    %-26s %.4g" % (c, acc[k][c]))
+
+
 def main():
+    if sys.argv[1] == "--counters":
+        return all_counters(sys.argv[2:])
     n = int(sys.argv[1])
     rd, wr = collect(sys.argv[2], "FETCH_SIZE"), collect(sys.argv[3], "WRITE_SIZE")
     out = {"input_bytes": n,

@@ -24,7 +24,9 @@
 #include "zamd_core.h"
 #include "../../include/zamd.h"
 
+#ifndef ZK_TILE
 #define ZK_TILE      16384u                   /* positions per k_match workgroup */
+#endif
 #define ZK_HALO      32768u
 #define ZK_WIN_BYTES (ZK_HALO + ZK_TILE + 320u)
 #define ZK_MATCH_THREADS 1024
