@@ -149,9 +149,11 @@ typedef struct zamd_inflate_seg {
     uint32_t win_avail, mode;
     uint64_t out_len, end_bit;          /* results */
     uint32_t status, final_seen;        /* results */
+    uint64_t stop_bit;                  /* ZAMD_INF_BLOCKSTOP: stop at the first block boundary at or behind this bit */
 } zamd_inflate_seg;
 #define ZAMD_INF_SYNCSTOP 1u
 #define ZAMD_INF_EXACT    2u            /* out_len must come out equal to out_cap */
+#define ZAMD_INF_BLOCKSTOP 4u           /* status 2 (as for a sync marker) when a block ends at or behind stop_bit */
 int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, zamd_inflate_seg *segs, uint64_t nseg,
                               const void *d_head_window, void *d_out, uint64_t out_bytes);
 /* Offsets just behind every 00 00 FF FF in d_in[from, n) (the pattern inflateSync looks for,
@@ -159,6 +161,14 @@ int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uint64_t comp_
  * receives at most cap offsets in no particular order; *count above cap means the list is
  * incomplete. */
 int zamd_find_sync_dev(zamd_engine *e, const void *d_in, uint64_t from, uint64_t n, uint64_t *h_list, uint32_t cap, uint32_t *count);
+/* Starting points inside a stream that has no sync markers: for every h_targets_bit[i] (a bit position in
+ * d_in) the first bit position in [target, target + window_bits) at which the header of a dynamic-Huffman block
+ * that is not the last one can be read completely and passes every check inflate makes before the block's first
+ * symbol (inflate.c:894-1012: counts in range, a complete code-length code, repeats in range, an end-of-block
+ * code, complete literal/length and distance codes), or ~0.  A hit is a guess, to be confirmed by a segment that
+ * ends there (ZAMD_INF_BLOCKSTOP).  The reference has no counterpart: inflateSync looks for 00 00 FF FF only. */
+int zamd_find_blocks_dev(zamd_engine *e, const void *d_in, uint64_t n, const uint64_t *h_targets_bit, uint32_t ntargets,
+                         uint64_t window_bits, uint64_t *h_found_bit);
 const char *zamd_inflate_message(uint32_t status);      /* the reference's msg strings, inflate.c:859-1202 */
 int zamd_inflate_last_error(zamd_engine *e, int64_t *segment, uint32_t *status);
 

@@ -32,10 +32,10 @@ class InflateSeg(C.Structure):
     """zamd_inflate_seg of include/zamd.h."""
     _fields_ = [("in_bit", C.c_uint64), ("in_end_bit", C.c_uint64), ("out_off", C.c_uint64), ("out_cap", C.c_uint64),
                 ("win_avail", C.c_uint32), ("mode", C.c_uint32), ("out_len", C.c_uint64), ("end_bit", C.c_uint64),
-                ("status", C.c_uint32), ("final_seen", C.c_uint32)]
+                ("status", C.c_uint32), ("final_seen", C.c_uint32), ("stop_bit", C.c_uint64)]
 
 
-INF_SYNCSTOP, INF_EXACT = 1, 2
+INF_SYNCSTOP, INF_EXACT, INF_BLOCKSTOP = 1, 2, 4
 
 
 def load_library() -> C.CDLL:
@@ -61,6 +61,8 @@ def load_library() -> C.CDLL:
     lib.zamd_engine_tune.restype = i32
     lib.zamd_find_sync_dev.argtypes = [vp, vp, u64, u64, C.POINTER(u64), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.zamd_find_sync_dev.restype = i32
+    lib.zamd_find_blocks_dev.argtypes = [vp, vp, u64, C.POINTER(u64), C.c_uint32, u64, C.POINTER(u64)]
+    lib.zamd_find_blocks_dev.restype = i32
     lib.zamd_engine_prime.argtypes = [vp, i32, i32]
     lib.zamd_engine_prime.restype = i32
     lib.zamd_checksums_dev.argtypes = [vp, vp, u64, u32, vp, vp]
@@ -328,6 +330,19 @@ class Engine:
             if cnt.value > cap:
                 raise ZamdError(-5, "zamd_find_sync_dev", "more markers than the list holds", -1)
             return sorted(lst[:cnt.value])
+        finally:
+            d.free()
+
+    def find_blocks(self, stream, targets_bit, window_bits):
+        """zamd_find_blocks_dev on host bytes: per target the first plausible dynamic-block start, or None."""
+        d = self.alloc(len(stream) + 16)
+        try:
+            d.upload(stream)
+            n = len(targets_bit)
+            tg = (C.c_uint64 * n)(*targets_bit)
+            out = (C.c_uint64 * n)()
+            _chk(self.lib.zamd_find_blocks_dev(self.handle, d.ptr, len(stream), tg, n, window_bits, out), "zamd_find_blocks_dev")
+            return [None if v == 0xffffffffffffffff else int(v) for v in out]
         finally:
             d.free()
 

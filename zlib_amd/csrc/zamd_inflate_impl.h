@@ -48,6 +48,7 @@ enum {
 };
 #define ZI_MODE_SYNCSTOP 1u
 #define ZI_MODE_EXACT    2u
+#define ZI_MODE_BLOCKSTOP 4u
 
 static const char *zi_message(uint32_t status)
 {
@@ -76,6 +77,7 @@ struct ZiSeg {
     uint32_t win_avail, mode;
     uint64_t out_len, end_bit;
     uint32_t status, final_seen;
+    uint64_t stop_bit;
 };
 
 /* Table entry: bits 0-3 code length (0 = no code this short), 4-7 number of extra
@@ -575,6 +577,7 @@ __global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t
         good_bit = B.bitpos; good_pos = pos;
         if (last) { final_seen = 1; status = ZI_OK_FINAL; break; }
         if (empty_stored && (S.mode & ZI_MODE_SYNCSTOP)) { status = ZI_OK_SYNC; break; }
+        if ((S.mode & ZI_MODE_BLOCKSTOP) && B.bitpos >= S.stop_bit) { status = ZI_OK_SYNC; break; }
     }
     if ((S.mode & ZI_MODE_EXACT) && status < 3 && good_pos != S.out_cap) status = ZI_ERR_LENGTH;
     if (lane == 0) {
@@ -596,7 +599,7 @@ __global__ void k_inf_setup(const uint64_t *chunk_off, uint64_t nchunks, uint32_
     uint64_t before = s.out_off + head_avail;
     s.win_avail = (uint32_t)(before < 32768 ? before : 32768);
     s.mode = ZI_MODE_EXACT;
-    s.out_len = 0; s.end_bit = 0; s.status = 0xffffffffu; s.final_seen = 0;
+    s.out_len = 0; s.end_bit = 0; s.status = 0xffffffffu; s.final_seen = 0; s.stop_bit = 0;
     segs[i] = s;
 }
 
@@ -932,6 +935,128 @@ extern "C" int zamd_find_sync_dev(zamd_engine *e, const void *d_in, uint64_t fro
     HIPCHK(hipStreamSynchronize(s));
     *count = c;                                     /* more than cap: the list is incomplete, the caller falls back */
     if (c && c <= cap) HIPCHK(hipMemcpy(h_list, z->d_scan, (uint64_t)c * 8, hipMemcpyDeviceToHost));
+    return ZAMD_OK;
+}
+
+/* ------------------------------------------------------------------ block-start search
+ * One wavefront per target; lane l of round r probes bit target + 64 r + l.  A probe reads what inflate reads
+ * between a block's first bit and its first symbol (inflate.c:894-1012) and applies inflate's checks, plus
+ * two that hold for every encoder of interest: the block is not the last one, and its literal/length code is
+ * complete.  The code-length code is decoded canonically from its length counts (no table): probes that get
+ * that far are rare. */
+__device__ __forceinline__ uint64_t zi_bits_at(const uint8_t *in, uint64_t nbytes, uint64_t bit)
+{
+    const uint64_t byte = bit >> 3;
+    uint64_t v = 0;
+    if (byte + 8 <= nbytes) __builtin_memcpy(&v, in + byte, 8);
+    else for (uint32_t i = 0; i < 8 && byte + i < nbytes; i++) v |= (uint64_t)in[byte + i] << (8u * i);
+    return v >> (bit & 7u);                      /* 57 bits or more */
+}
+
+__device__ bool zi_probe_block(const uint8_t *in, uint64_t nbytes, uint64_t bit)
+{
+    const uint64_t end = nbytes * 8ull;
+    if (bit + 17 + 12 > end) return false;
+    uint64_t b = zi_bits_at(in, nbytes, bit);
+    if ((b & 7u) != 4u) return false;                                  /* BFINAL 0, BTYPE 2 */
+    const uint32_t nlen = ((uint32_t)(b >> 3) & 31u) + 257u, ndist = ((uint32_t)(b >> 8) & 31u) + 1u, ncode = ((uint32_t)(b >> 13) & 15u) + 4u;
+    if (nlen > 286 || ndist > 30) return false;
+    uint64_t pos = bit + 17;
+    b = zi_bits_at(in, nbytes, pos);
+    uint64_t pk = 0, cnt = 0;                                          /* 3 bits per symbol; 5 bits per length */
+    uint32_t kraft = 0, last_cl = 0;
+    for (uint32_t i = 0; i < ncode; i++) {
+        const uint32_t l = (uint32_t)(b >> (3u * i)) & 7u;
+        last_cl = l;
+        pk |= (uint64_t)l << (3u * zi_order[i]);
+        if (l) { kraft += 128u >> l; cnt += 1ull << (5u * l); }
+    }
+    pos += 3ull * ncode;
+    if (kraft != 128u) return false;                                   /* inflate wants this code complete */
+    /* an encoder sends no trailing zero lengths (trees.c:815-821, 842-848 send max_blindex + 1, max_code + 1 codes):
+     * not a rule of the format, but a guess need not cover every stream */
+    if (ncode > 4 && last_cl == 0) return false;
+    const uint32_t total = nlen + ndist;
+    uint32_t idx = 0, prev = 0, sumL = 0, sumD = 0, nzD = 0, maxD = 0, last_l = 0, last_d = 0;
+    bool eob = false;
+    while (idx < total) {
+        if (pos + 14 > end) return false;
+        b = zi_bits_at(in, nbytes, pos);
+        /* canonical decode: codes of one length are consecutive, shorter codes come first */
+        uint32_t code = 0, first = 0, index = 0, len = 1, sym = 99;
+        for (; len <= 7; len++) {
+            code |= (uint32_t)(b >> (len - 1)) & 1u;
+            const uint32_t c = (uint32_t)(cnt >> (5u * len)) & 31u;
+            if (code < first + c) {
+                uint32_t k = index + (code - first);                   /* k-th symbol in (length, symbol) order */
+                for (uint32_t L = 1; L <= 7 && sym == 99; L++)
+                    for (uint32_t s = 0; s < 19; s++)
+                        if (((uint32_t)(pk >> (3u * s)) & 7u) == L) { if (k == 0) { sym = s; break; } k--; }
+                break;
+            }
+            index += c; first += c; first <<= 1; code <<= 1;
+        }
+        if (sym == 99) return false;
+        pos += len; b >>= len;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16) { if (idx == 0) return false; rep = 3 + ((uint32_t)b & 3u); pos += 2; val = prev; }
+        else if (sym == 17) { rep = 3 + ((uint32_t)b & 7u); pos += 3; val = 0; }
+        else if (sym == 18) { rep = 11 + ((uint32_t)b & 127u); pos += 7; val = 0; }
+        if (idx + rep > total) return false;
+        prev = val;
+        if (val) {
+            for (uint32_t j = 0; j < rep; j++) {
+                const uint32_t i = idx + j;
+                if (i < nlen) { sumL += 32768u >> val; if (i == 256) eob = true; if (i == nlen - 1) last_l = val; }
+                else { sumD += 32768u >> val; nzD++; if (val > maxD) maxD = val; if (i == total - 1) last_d = val; }
+            }
+        }
+        idx += rep;
+    }
+    if (pos > end || !eob) return false;
+    if (sumL != 32768u) return false;
+    if ((nlen > 257 && last_l == 0) || (ndist > 1 && last_d == 0)) return false;
+    return sumD == 32768u || (nzD <= 1 && maxD <= 1);
+}
+
+__global__ __launch_bounds__(64) void k_inf_blockscan(const uint8_t *in, uint64_t nbytes, const uint64_t *targets, uint32_t ntargets,
+                                                      uint64_t window_bits, uint64_t *found)
+{
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    if (t >= ntargets) return;
+    const uint64_t t0 = targets[t];
+    uint64_t hit = ~0ull;
+    for (uint64_t r = 0; r < window_bits; r += 64) {
+        const uint64_t bit = t0 + r + lane;
+        const bool ok = r + lane < window_bits && zi_probe_block(in, nbytes, bit);
+        const unsigned long long m = __ballot(ok);
+        if (m) { hit = t0 + r + (uint64_t)(__ffsll((long long)m) - 1); break; }
+    }
+    if (lane == 0) found[t] = hit;
+}
+
+extern "C" int zamd_find_blocks_dev(zamd_engine *e, const void *d_in, uint64_t n, const uint64_t *h_targets_bit, uint32_t ntargets,
+                                    uint64_t window_bits, uint64_t *h_found_bit)
+{
+    if (!e || !d_in || !h_targets_bit || !h_found_bit) return ZAMD_STREAM_ERROR;
+    if (ntargets == 0) return ZAMD_OK;
+    for (uint32_t i = 0; i < ntargets; i++) if (h_targets_bit[i] > n * 8ull) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = zi_ensure(e, 1, 0, false);
+    if (rc) return rc;
+    ZiState *z = e->inf;
+    const uint32_t need = 2u * ntargets;
+    if (z->scan_cap < need) {
+        hipFree(z->d_scan); z->d_scan = nullptr; z->scan_cap = 0;
+        if (hipMalloc((void **)&z->d_scan, (uint64_t)need * 8) != hipSuccess) return ZAMD_MEM_ERROR;
+        z->scan_cap = need;
+    }
+    hipStream_t s = e->st[0];
+    HIPCHK(hipMemcpyAsync(z->d_scan, h_targets_bit, (uint64_t)ntargets * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_inf_blockscan, dim3(ntargets), dim3(64), 0, s, (const uint8_t *)d_in, n, z->d_scan, ntargets, window_bits, z->d_scan + ntargets);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_found_bit, z->d_scan + ntargets, (uint64_t)ntargets * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
     return ZAMD_OK;
 }
 

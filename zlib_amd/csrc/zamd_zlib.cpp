@@ -791,12 +791,76 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
             g.out_off = 0; g.out_cap = guess ? spec_out : (~0ull >> 2); g.win_avail = win; g.mode = ZAMD_INF_SYNCSTOP;
             segs.push_back(g);
         };
-        add(s->bit_off, (uint32_t)s->hist.size(), false);
-        for (uint64_t c : cands) if (c * 8 > s->bit_off && c * 8 < end_bits && segs.size() < (1u << 20)) add(c * 8, HIST, true);
+        // Stretches without sync markers (streams of other producers have none at all): guessed starts of
+        // dynamic blocks, one per STEP of input, found on the GPU.  A segment stops at the first block boundary
+        // at or behind the next guess; a guess that is no block start just ends the chain there for this round.
+        std::vector<uint64_t> bc;
+        {
+            static const uint64_t STEP = (getenv("ZAMD_Z_BLOCKSCAN_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_KIB"), nullptr, 10) : 128) * 8192ull;
+            if (STEP && end_bits > s->bit_off + 2 * STEP) {
+                std::vector<uint64_t> tg;
+                size_t ci = 0;
+                for (uint64_t t = s->bit_off + STEP; t + STEP / 2 <= end_bits && tg.size() < (1u << 16); t += STEP) {
+                    while (ci < cands.size() && cands[ci] * 8 + STEP / 2 < t) ci++;
+                    if (ci < cands.size() && cands[ci] * 8 < t + STEP / 2) continue;     // a marker close by is a start already
+                    tg.push_back(t);
+                }
+                if (!tg.empty()) {
+                    std::vector<uint64_t> found(tg.size());
+                    if (zamd_find_blocks_dev(e, g_gpu.d_in, in_n, tg.data(), (uint32_t)tg.size(), STEP, found.data()) != 0) return Z_MEM_ERROR;
+                    for (uint64_t f : found) if (f != ~0ull && f > s->bit_off && f < end_bits && (bc.empty() || bc.back() < f)) bc.push_back(f);
+                }
+            }
+        }
+        tr.lap("blockscan");
+        {
+            std::vector<uint64_t> starts;
+            for (uint64_t c : cands) if (c * 8 > s->bit_off && c * 8 < end_bits) starts.push_back(c * 8);
+            starts.insert(starts.end(), bc.begin(), bc.end());
+            std::sort(starts.begin(), starts.end());
+            starts.erase(std::unique(starts.begin(), starts.end()), starts.end());
+            add(s->bit_off, (uint32_t)s->hist.size(), false);
+            for (uint64_t b : starts) if (segs.size() < (1u << 20)) add(b, HIST, true);
+            size_t bi = 0;
+            for (zamd_inflate_seg &g : segs) {
+                while (bi < bc.size() && bc[bi] <= g.in_bit) bi++;
+                if (bi < bc.size()) { g.mode |= ZAMD_INF_BLOCKSTOP; g.stop_bit = bc[bi]; }
+            }
+        }
 
         if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
 
         tr.lap("count");
+        // A guess that is no block start leaves the segment in front of it ending where no segment starts.  Such
+        // ends get segments of their own, all of them in one more pass (and again, should one of those end the same way).
+        for (int round = 0; round < 6 && !bc.empty(); round++) {
+            std::vector<uint64_t> loose;
+            for (const zamd_inflate_seg &g : segs) {
+                if (g.status != 2 || g.end_bit >= end_bits) continue;
+                size_t lo = 0, hi = segs.size();
+                while (lo < hi) { size_t mid = (lo + hi) / 2; if (segs[mid].in_bit < g.end_bit) lo = mid + 1; else hi = mid; }
+                if (lo >= segs.size() || segs[lo].in_bit != g.end_bit) loose.push_back(g.end_bit);
+            }
+            if (loose.empty()) break;
+            std::sort(loose.begin(), loose.end());
+            loose.erase(std::unique(loose.begin(), loose.end()), loose.end());
+            std::vector<zamd_inflate_seg> fix;
+            size_t bi = 0;
+            for (uint64_t b : loose) {
+                zamd_inflate_seg g; memset(&g, 0, sizeof g);
+                g.in_bit = b; g.in_end_bit = b + spec_bits < end_bits ? b + spec_bits : end_bits;
+                g.out_cap = spec_out; g.win_avail = HIST; g.mode = ZAMD_INF_SYNCSTOP;
+                while (bi < bc.size() && bc[bi] <= b) bi++;
+                if (bi < bc.size()) { g.mode |= ZAMD_INF_BLOCKSTOP; g.stop_bit = bc[bi]; }
+                fix.push_back(g);
+            }
+            if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, fix.data(), fix.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
+            std::vector<zamd_inflate_seg> merged(segs.size() + fix.size());
+            std::merge(segs.begin(), segs.end(), fix.begin(), fix.end(), merged.begin(),
+                       [](const zamd_inflate_seg &a, const zamd_inflate_seg &b) { return a.in_bit < b.in_bit; });
+            segs.swap(merged);
+        }
+        tr.lap("repair");
         // follow the chain of segments from the known block start
         size_t idx = 0;
         for (;;) {
