@@ -939,7 +939,7 @@ extern "C" int zamd_find_sync_dev(zamd_engine *e, const void *d_in, uint64_t fro
 }
 
 /* ------------------------------------------------------------------ block-start search
- * One wavefront per target; lane l of round r probes bit target + 64 r + l.  A probe reads what inflate reads
+ * One workgroup per target; lane l of round r probes bit target + 64 r + l.  A probe reads what inflate reads
  * between a block's first bit and its first symbol (inflate.c:894-1012) and applies inflate's checks, plus
  * two that hold for every encoder of interest: the block is not the last one, and its literal/length code is
  * complete.  The code-length code is decoded canonically from its length counts (no table): probes that get
@@ -977,31 +977,45 @@ __device__ bool zi_probe_block(const uint8_t *in, uint64_t nbytes, uint64_t bit)
      * not a rule of the format, but a guess need not cover every stream */
     if (ncode > 4 && last_cl == 0) return false;
     const uint32_t total = nlen + ndist;
+    /* symbols in (length, symbol) order, 5 bits each: the order canonical codes are handed out in */
+    uint64_t so0 = 0, so1 = 0;
+    {
+        uint32_t k = 0;
+        for (uint32_t L = 1; L <= 7; L++)
+            for (uint32_t sy = 0; sy < 19; sy++)
+                if (((uint32_t)(pk >> (3u * sy)) & 7u) == L) {
+                    if (k < 12) so0 |= (uint64_t)sy << (5u * k); else so1 |= (uint64_t)sy << (5u * (k - 12u));
+                    k++;
+                }
+    }
     uint32_t idx = 0, prev = 0, sumL = 0, sumD = 0, nzD = 0, maxD = 0, last_l = 0, last_d = 0;
     bool eob = false;
+    uint32_t have = 0;                                                 /* valid bits in b */
     while (idx < total) {
-        if (pos + 14 > end) return false;
-        b = zi_bits_at(in, nbytes, pos);
+        if (have < 14) {
+            if (pos + 14 > end) return false;
+            b = zi_bits_at(in, nbytes, pos); have = 57;
+        }
         /* canonical decode: codes of one length are consecutive, shorter codes come first */
         uint32_t code = 0, first = 0, index = 0, len = 1, sym = 99;
         for (; len <= 7; len++) {
             code |= (uint32_t)(b >> (len - 1)) & 1u;
             const uint32_t c = (uint32_t)(cnt >> (5u * len)) & 31u;
             if (code < first + c) {
-                uint32_t k = index + (code - first);                   /* k-th symbol in (length, symbol) order */
-                for (uint32_t L = 1; L <= 7 && sym == 99; L++)
-                    for (uint32_t s = 0; s < 19; s++)
-                        if (((uint32_t)(pk >> (3u * s)) & 7u) == L) { if (k == 0) { sym = s; break; } k--; }
+                const uint32_t k = index + (code - first);
+                sym = k < 12 ? (uint32_t)(so0 >> (5u * k)) & 31u : (uint32_t)(so1 >> (5u * (k - 12u))) & 31u;
                 break;
             }
             index += c; first += c; first <<= 1; code <<= 1;
         }
         if (sym == 99) return false;
-        pos += len; b >>= len;
+        uint32_t used = len;
+        b >>= len;
         uint32_t rep = 1, val = sym;
-        if (sym == 16) { if (idx == 0) return false; rep = 3 + ((uint32_t)b & 3u); pos += 2; val = prev; }
-        else if (sym == 17) { rep = 3 + ((uint32_t)b & 7u); pos += 3; val = 0; }
-        else if (sym == 18) { rep = 11 + ((uint32_t)b & 127u); pos += 7; val = 0; }
+        if (sym == 16) { if (idx == 0) return false; rep = 3 + ((uint32_t)b & 3u); used += 2; b >>= 2; val = prev; }
+        else if (sym == 17) { rep = 3 + ((uint32_t)b & 7u); used += 3; b >>= 3; val = 0; }
+        else if (sym == 18) { rep = 11 + ((uint32_t)b & 127u); used += 7; b >>= 7; val = 0; }
+        pos += used; have -= used;
         if (idx + rep > total) return false;
         prev = val;
         if (val) {
@@ -1010,6 +1024,7 @@ __device__ bool zi_probe_block(const uint8_t *in, uint64_t nbytes, uint64_t bit)
                 if (i < nlen) { sumL += 32768u >> val; if (i == 256) eob = true; if (i == nlen - 1) last_l = val; }
                 else { sumD += 32768u >> val; nzD++; if (val > maxD) maxD = val; if (i == total - 1) last_d = val; }
             }
+            if (sumL > 32768u || sumD > 32768u) return false;          /* over-subscribed already */
         }
         idx += rep;
     }
@@ -1019,20 +1034,25 @@ __device__ bool zi_probe_block(const uint8_t *in, uint64_t nbytes, uint64_t bit)
     return sumD == 32768u || (nzD <= 1 && maxD <= 1);
 }
 
-__global__ __launch_bounds__(64) void k_inf_blockscan(const uint8_t *in, uint64_t nbytes, const uint64_t *targets, uint32_t ntargets,
-                                                      uint64_t window_bits, uint64_t *found)
+#define ZI_BSCAN_THREADS 1024
+__global__ __launch_bounds__(ZI_BSCAN_THREADS) void k_inf_blockscan(const uint8_t *in, uint64_t nbytes, const uint64_t *targets, uint32_t ntargets,
+                                                                   uint64_t window_bits, uint64_t *found)
 {
-    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    /* the 16 wavefronts of a workgroup take the rounds of one target in turn; a hit ends every round behind it */
+    __shared__ unsigned long long s_hit;
+    const uint32_t t = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (t >= ntargets) return;
+    if (threadIdx.x == 0) s_hit = ~0ull;
+    __syncthreads();
     const uint64_t t0 = targets[t];
-    uint64_t hit = ~0ull;
-    for (uint64_t r = 0; r < window_bits; r += 64) {
-        const uint64_t bit = t0 + r + lane;
-        const bool ok = r + lane < window_bits && zi_probe_block(in, nbytes, bit);
+    for (uint64_t r = 64ull * wave; r < window_bits; r += ZI_BSCAN_THREADS) {
+        if (*(volatile unsigned long long *)&s_hit < t0 + r) break;
+        const bool ok = r + lane < window_bits && zi_probe_block(in, nbytes, t0 + r + lane);
         const unsigned long long m = __ballot(ok);
-        if (m) { hit = t0 + r + (uint64_t)(__ffsll((long long)m) - 1); break; }
+        if (m) { if (lane == 0) atomicMin(&s_hit, (unsigned long long)(t0 + r + (uint64_t)(__ffsll((long long)m) - 1))); break; }
     }
-    if (lane == 0) found[t] = hit;
+    __syncthreads();
+    if (threadIdx.x == 0) found[t] = s_hit;
 }
 
 extern "C" int zamd_find_blocks_dev(zamd_engine *e, const void *d_in, uint64_t n, const uint64_t *h_targets_bit, uint32_t ntargets,
@@ -1053,7 +1073,7 @@ extern "C" int zamd_find_blocks_dev(zamd_engine *e, const void *d_in, uint64_t n
     }
     hipStream_t s = e->st[0];
     HIPCHK(hipMemcpyAsync(z->d_scan, h_targets_bit, (uint64_t)ntargets * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_inf_blockscan, dim3(ntargets), dim3(64), 0, s, (const uint8_t *)d_in, n, z->d_scan, ntargets, window_bits, z->d_scan + ntargets);
+    hipLaunchKernelGGL(k_inf_blockscan, dim3(ntargets), dim3(ZI_BSCAN_THREADS), 0, s, (const uint8_t *)d_in, n, z->d_scan, ntargets, window_bits, z->d_scan + ntargets);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_found_bit, z->d_scan + ntargets, (uint64_t)ntargets * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -796,7 +796,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         // at or behind the next guess; a guess that is no block start just ends the chain there for this round.
         std::vector<uint64_t> bc;
         {
-            static const uint64_t STEP = (getenv("ZAMD_Z_BLOCKSCAN_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_KIB"), nullptr, 10) : 128) * 8192ull;
+            static const uint64_t STEP = (getenv("ZAMD_Z_BLOCKSCAN_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_KIB"), nullptr, 10) : 32) * 8192ull;
             if (STEP && end_bits > s->bit_off + 2 * STEP) {
                 std::vector<uint64_t> tg;
                 size_t ci = 0;
