@@ -962,20 +962,25 @@ __device__ bool zi_probe_block(const uint8_t *in, uint64_t nbytes, uint64_t bit)
     const uint32_t nlen = ((uint32_t)(b >> 3) & 31u) + 257u, ndist = ((uint32_t)(b >> 8) & 31u) + 1u, ncode = ((uint32_t)(b >> 13) & 15u) + 4u;
     if (nlen > 286 || ndist > 30) return false;
     uint64_t pos = bit + 17;
-    b = zi_bits_at(in, nbytes, pos);
-    uint64_t pk = 0, cnt = 0;                                          /* 3 bits per symbol; 5 bits per length */
-    uint32_t kraft = 0, last_cl = 0;
-    for (uint32_t i = 0; i < ncode; i++) {
-        const uint32_t l = (uint32_t)(b >> (3u * i)) & 7u;
-        last_cl = l;
-        pk |= (uint64_t)l << (3u * zi_order[i]);
-        if (l) { kraft += 128u >> l; cnt += 1ull << (5u * l); }
+    b = zi_bits_at(in, nbytes, pos) & ((1ull << (3u * ncode)) - 1ull);
+    /* how many of the 3-bit lengths have each value, from the three bit planes: the code must be complete
+     * (inflate wants that, inflate.c:929) — the test that ends nearly every probe that got this far */
+    uint64_t cnt;
+    {
+        const uint64_t M = 0x1249249249249249ull;
+        const uint64_t a0 = b & M, a1 = (b >> 1) & M, a2 = (b >> 2) & M, n0 = a0 ^ M, n1 = a1 ^ M, n2 = a2 ^ M;
+        const uint32_t c1 = __popcll(a0 & n1 & n2), c2 = __popcll(n0 & a1 & n2), c3 = __popcll(a0 & a1 & n2), c4 = __popcll(n0 & n1 & a2),
+                       c5 = __popcll(a0 & n1 & a2), c6 = __popcll(n0 & a1 & a2), c7 = __popcll(a0 & a1 & a2);
+        if (64u * c1 + 32u * c2 + 16u * c3 + 8u * c4 + 4u * c5 + 2u * c6 + c7 != 128u) return false;
+        cnt = ((uint64_t)c1 << 5) | ((uint64_t)c2 << 10) | ((uint64_t)c3 << 15) | ((uint64_t)c4 << 20) | ((uint64_t)c5 << 25) |
+              ((uint64_t)c6 << 30) | ((uint64_t)c7 << 35);
     }
-    pos += 3ull * ncode;
-    if (kraft != 128u) return false;                                   /* inflate wants this code complete */
     /* an encoder sends no trailing zero lengths (trees.c:815-821, 842-848 send max_blindex + 1, max_code + 1 codes):
      * not a rule of the format, but a guess need not cover every stream */
-    if (ncode > 4 && last_cl == 0) return false;
+    if (ncode > 4 && ((b >> (3u * (ncode - 1u))) & 7u) == 0) return false;
+    uint64_t pk = 0;                                                   /* 3 bits per symbol */
+    for (uint32_t i = 0; i < ncode; i++) pk |= ((b >> (3u * i)) & 7ull) << (3u * zi_order[i]);
+    pos += 3ull * ncode;
     const uint32_t total = nlen + ndist;
     /* symbols in (length, symbol) order, 5 bits each: the order canonical codes are handed out in */
     uint64_t so0 = 0, so1 = 0;

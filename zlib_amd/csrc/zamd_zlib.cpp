@@ -798,11 +798,16 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         {
             static const uint64_t STEP = (getenv("ZAMD_Z_BLOCKSCAN_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_KIB"), nullptr, 10) : 32) * 8192ull;
             if (STEP && end_bits > s->bit_off + 2 * STEP) {
+                // only where sync markers are further apart than GAP: a stream cut into chunks has starts enough
+                static const uint64_t GAP = (getenv("ZAMD_Z_BLOCKSCAN_GAP_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_GAP_KIB"), nullptr, 10) : 2048) * 8192ull;
                 std::vector<uint64_t> tg;
-                size_t ci = 0;
+                size_t ci = 0;                                   // first marker behind t
                 for (uint64_t t = s->bit_off + STEP; t + STEP / 2 <= end_bits && tg.size() < (1u << 16); t += STEP) {
-                    while (ci < cands.size() && cands[ci] * 8 + STEP / 2 < t) ci++;
-                    if (ci < cands.size() && cands[ci] * 8 < t + STEP / 2) continue;     // a marker close by is a start already
+                    while (ci < cands.size() && cands[ci] * 8 <= t) ci++;
+                    const uint64_t before = ci > 0 && cands[ci - 1] * 8 > s->bit_off ? cands[ci - 1] * 8 : s->bit_off;
+                    const uint64_t behind = ci < cands.size() && cands[ci] * 8 < end_bits ? cands[ci] * 8 : end_bits;
+                    if (behind - before < GAP) continue;
+                    if (t - before < STEP / 2 || behind - t < STEP / 2) continue;        // a marker close by is a start already
                     tg.push_back(t);
                 }
                 if (!tg.empty()) {
