@@ -290,7 +290,12 @@ __device__ __forceinline__ uint32_t zi_slow(const ZiTab &T, uint32_t bits, uint3
 }
 
 template <bool WRITE>
-__global__ __launch_bounds__(64) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16)
+/* registers, not LDS, set the wavefronts per SIMD: 84 registers allow 5; held to 80 (two spilled values) 6 fit and decode
+ * 3 % faster, held to 72 (five spills) 7 fit and it is slower */
+#ifndef ZI_WAVES_PER_SIMD
+#define ZI_WAVES_PER_SIMD 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER_SIMD, ZI_WAVES_PER_SIMD))) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16)
 {
     __shared__ ZiLds L;
     const uint32_t lane = threadIdx.x;
