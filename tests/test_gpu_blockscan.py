@@ -109,3 +109,25 @@ def test_inflate_of_a_foreign_stream_in_pieces():
     assert want_msg is not None and msg in want_msg            # the system zlib words its errors as the reference does
     k = len(data) * 2 // 5
     assert out[:k] == data[:k]
+
+
+def test_planted_block_headers_are_guessed_and_repaired(engine):
+    """Stored blocks that carry the bytes of a real dynamic-block header: the search takes them for block starts,
+    the segments in front of them end elsewhere, and inflate() mends the chain in a further pass."""
+    text = O.corpus(12 * (1 << 20), 0, 330)
+    header = _raw(text[:1 << 20], 6)[:256]               # a dynamic block's first bytes (BFINAL 0: the input is long)
+    assert header[0] & 7 == 4
+    noise = bytearray(O.corpus(6 * (1 << 20), 1, 331))
+    planted = list(range(5000, len(noise) - 4096, 40000))
+    for at in planted:
+        noise[at:at + len(header)] = header
+    data = text[:6 << 20] + bytes(noise) + text[6 << 20:]
+    comp = _raw(data, 6)
+    # the planted bytes are in the stream verbatim (stored blocks), and the search finds some of them
+    first = comp.find(header, 4096)                       # (the stream itself begins with these bytes)
+    assert first > 0
+    hits = engine.find_blocks(comp, [first * 8 - 4096], 1 << 16)
+    assert hits == [first * 8]
+    rc, out, msg, rest, _ = Z.inflate_stream(b"\x78\x9c" + comp + zlib.adler32(data).to_bytes(4, "big"), out_step=len(data) + 64)
+    assert rc == Z.Z_STREAM_END, msg
+    assert out == data

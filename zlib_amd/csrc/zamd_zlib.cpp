@@ -804,9 +804,10 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
                 size_t ci = 0;                                   // first marker behind t
                 for (uint64_t t = s->bit_off + STEP; t + STEP / 2 <= end_bits && tg.size() < (1u << 16); t += STEP) {
                     while (ci < cands.size() && cands[ci] * 8 <= t) ci++;
-                    const uint64_t before = ci > 0 && cands[ci - 1] * 8 > s->bit_off ? cands[ci - 1] * 8 : s->bit_off;
-                    const uint64_t behind = ci < cands.size() && cands[ci] * 8 < end_bits ? cands[ci] * 8 : end_bits;
-                    if (behind - before < GAP) continue;
+                    const bool m0 = ci > 0 && cands[ci - 1] * 8 > s->bit_off, m1 = ci < cands.size() && cands[ci] * 8 < end_bits;
+                    const uint64_t before = m0 ? cands[ci - 1] * 8 : s->bit_off;
+                    const uint64_t behind = m1 ? cands[ci] * 8 : end_bits;
+                    if ((m0 || m1) && behind - before < GAP) continue;    // (a short stream without any marker is searched)
                     if (t - before < STEP / 2 || behind - t < STEP / 2) continue;        // a marker close by is a start already
                     tg.push_back(t);
                 }
