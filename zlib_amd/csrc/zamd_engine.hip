@@ -30,6 +30,9 @@
 #define ZK_HALO      32768u
 #define ZK_WIN_BYTES (ZK_HALO + ZK_TILE + 320u)
 #define ZK_MATCH_THREADS 1024
+#ifndef ZK_MATCH_STEPS
+#define ZK_MATCH_STEPS 8                     /* candidate steps between two looks at the number of stopped lanes */
+#endif
 #define ZK_PLAN_THREADS  64                   /* one wave per block: the tree builds are serial, what counts is blocks in flight */
 #define ZK_EMIT_THREADS  256
 #define ZK_STAGE_WORDS   400                  /* 31 + 256*48 + 31 bits */
@@ -385,9 +388,9 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
             c = (la0 - n - best) + peek_off;
         } else {
 #pragma unroll 1
-        for (int it = 0; it < 8; it++) {
+        for (int it = 0; it < 64 / ZK_MATCH_STEPS; it++) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < ZK_MATCH_STEPS; u++) {
                 if (MODE == 3 && wm >= 0) continue;               /* MODE 3: stopped lanes are masked off, their LDS reads with them */
                 uint32_t v;
                 if (MODE == 1) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
