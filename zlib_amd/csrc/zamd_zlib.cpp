@@ -878,7 +878,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
                 if (one.out_len == 0) { strm->msg = "deflate block too large for the GPU engine"; s->mode = IM_MEM; return Z_MEM_ERROR; }
                 g = one; g.status = 3;
             }
-            if ((produced + g.out_len > s->out_batch || chain.size() >= 8192) && !chain.empty()) break;
+            if ((produced + g.out_len > s->out_batch || chain.size() >= 32768) && !chain.empty()) break;
             if (g.end_bit > g.in_bit || g.status == 1) {
                 g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
                 g.out_off = produced; g.out_cap = g.out_len; g.in_end_bit = g.end_bit; g.mode = ZAMD_INF_EXACT;
