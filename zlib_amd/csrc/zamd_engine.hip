@@ -1277,6 +1277,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                 else if (mv == 8) hipLaunchKernelGGL((k_match<0, 24>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 9) hipLaunchKernelGGL((k_match<0, 32>), grid, blk, 0, s, J, tiles, rle);
                 else if (mv == 21) hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 22) hipLaunchKernelGGL((k_match<3, 24>), grid, blk, 0, s, J, tiles, rle);
+                else if (mv == 23) hipLaunchKernelGGL((k_match<3, 32>), grid, blk, 0, s, J, tiles, rle);
                 else hipLaunchKernelGGL((k_match<3, 28>), grid, blk, 0, s, J, tiles, rle);
             }
             tm_end(e, s, slot);
