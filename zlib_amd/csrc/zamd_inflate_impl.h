@@ -944,7 +944,7 @@ extern "C" int zamd_find_sync_dev(zamd_engine *e, const void *d_in, uint64_t fro
 }
 
 /* ------------------------------------------------------------------ block-start search
- * One workgroup per target; lane l of round r probes bit target + 64 r + l.  A probe reads what inflate reads
+ * One workgroup per target; lane l of round r probes the bits target + 512 r + 8 l .. + 7.  A probe reads what inflate reads
  * between a block's first bit and its first symbol (inflate.c:894-1012) and applies inflate's checks, plus
  * two that hold for every encoder of interest: the block is not the last one, and its literal/length code is
  * complete.  The code-length code is decoded canonically from its length counts (no table): probes that get
@@ -1055,11 +1055,26 @@ __global__ __launch_bounds__(ZI_BSCAN_THREADS) void k_inf_blockscan(const uint8_
     if (threadIdx.x == 0) s_hit = ~0ull;
     __syncthreads();
     const uint64_t t0 = targets[t];
-    for (uint64_t r = 64ull * wave; r < window_bits; r += ZI_BSCAN_THREADS) {
+    /* a lane takes the eight bit positions of one byte: one load, the three header fields that need no further
+     * reading tested for all eight, the full probe only where they pass (one position in nine) */
+    for (uint64_t r = 512ull * wave; r < window_bits; r += 512ull * (ZI_BSCAN_THREADS / 64)) {
         if (*(volatile unsigned long long *)&s_hit < t0 + r) break;
-        const bool ok = r + lane < window_bits && zi_probe_block(in, nbytes, t0 + r + lane);
-        const unsigned long long m = __ballot(ok);
-        if (m) { if (lane == 0) atomicMin(&s_hit, (unsigned long long)(t0 + r + (uint64_t)(__ffsll((long long)m) - 1))); break; }
+        const uint64_t off = r + 8ull * lane, bit0 = t0 + off;
+        unsigned long long hit = ~0ull;
+        if (off < window_bits) {
+            const uint64_t w = zi_bits_at(in, nbytes, bit0);
+            for (uint32_t s8 = 0; s8 < 8; s8++) {
+                const uint32_t h = (uint32_t)(w >> s8);
+                if ((h & 7u) == 4u && ((h >> 3) & 31u) <= 29u && ((h >> 8) & 31u) <= 29u && off + s8 < window_bits &&
+                    zi_probe_block(in, nbytes, bit0 + s8)) { hit = bit0 + s8; break; }
+            }
+        }
+        const unsigned long long m = __ballot(hit != ~0ull);
+        if (m) {
+            /* lanes hold increasing positions: the lowest lane with a hit has the first one of this round */
+            if (lane == (uint32_t)(__ffsll((long long)m) - 1)) atomicMin(&s_hit, hit);
+            break;
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) found[t] = s_hit;
