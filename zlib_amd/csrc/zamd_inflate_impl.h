@@ -958,6 +958,25 @@ __device__ __forceinline__ uint64_t zi_bits_at(const uint8_t *in, uint64_t nbyte
     return v >> (bit & 7u);                      /* 57 bits or more */
 }
 
+/* The part of the probe that reads 74 bits at most: block type, counts, and a complete code-length code without
+ * trailing zero lengths.  One position in about five hundred passes it on data that holds no block start. */
+__device__ bool zi_probe_head(const uint8_t *in, uint64_t nbytes, uint64_t bit)
+{
+    const uint64_t end = nbytes * 8ull;
+    if (bit + 17 + 12 > end) return false;
+    uint64_t b = zi_bits_at(in, nbytes, bit);
+    if ((b & 7u) != 4u) return false;
+    const uint32_t nlen = ((uint32_t)(b >> 3) & 31u) + 257u, ndist = ((uint32_t)(b >> 8) & 31u) + 1u, ncode = ((uint32_t)(b >> 13) & 15u) + 4u;
+    if (nlen > 286 || ndist > 30) return false;
+    b = zi_bits_at(in, nbytes, bit + 17) & ((1ull << (3u * ncode)) - 1ull);
+    const uint64_t M = 0x1249249249249249ull;
+    const uint64_t a0 = b & M, a1 = (b >> 1) & M, a2 = (b >> 2) & M, n0 = a0 ^ M, n1 = a1 ^ M, n2 = a2 ^ M;
+    const uint32_t kraft = 64u * __popcll(a0 & n1 & n2) + 32u * __popcll(n0 & a1 & n2) + 16u * __popcll(a0 & a1 & n2) + 8u * __popcll(n0 & n1 & a2) +
+                           4u * __popcll(a0 & n1 & a2) + 2u * __popcll(n0 & a1 & a2) + __popcll(a0 & a1 & a2);
+    if (kraft != 128u) return false;
+    return ncode == 4 || ((b >> (3u * (ncode - 1u))) & 7u) != 0;
+}
+
 __device__ bool zi_probe_block(const uint8_t *in, uint64_t nbytes, uint64_t bit)
 {
     const uint64_t end = nbytes * 8ull;
@@ -1050,32 +1069,52 @@ __global__ __launch_bounds__(ZI_BSCAN_THREADS) void k_inf_blockscan(const uint8_
 {
     /* the 16 wavefronts of a workgroup take the rounds of one target in turn; a hit ends every round behind it */
     __shared__ unsigned long long s_hit;
+    __shared__ unsigned long long s_q[ZI_BSCAN_THREADS / 64][128];
     const uint32_t t = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (t >= ntargets) return;
     if (threadIdx.x == 0) s_hit = ~0ull;
     __syncthreads();
     const uint64_t t0 = targets[t];
-    /* a lane takes the eight bit positions of one byte: one load, the three header fields that need no further
-     * reading tested for all eight, the full probe only where they pass (one position in nine) */
+    /* A lane takes the eight bit positions of one byte (one load).  Positions that pass the short part of the probe
+     * are queued per wavefront and get the long part — the decode of up to 316 code lengths — 64 at a time, one per
+     * lane: done where they are found, one such position would hold up the 63 other lanes of its round. */
+    unsigned long long *q = s_q[wave];
+    uint32_t qn = 0;
+    auto drain = [&](uint32_t n) {
+        __threadfence_block();
+        if (lane < n) {
+            const unsigned long long pos = q[lane];
+            if (zi_probe_block(in, nbytes, pos)) atomicMin(&s_hit, pos);
+        }
+        unsigned long long keep = 0;
+        if (lane < qn - n) keep = q[n + lane];
+        __threadfence_block();
+        if (lane < qn - n) q[lane] = keep;
+        qn -= n;
+    };
     for (uint64_t r = 512ull * wave; r < window_bits; r += 512ull * (ZI_BSCAN_THREADS / 64)) {
         if (*(volatile unsigned long long *)&s_hit < t0 + r) break;
         const uint64_t off = r + 8ull * lane, bit0 = t0 + off;
-        unsigned long long hit = ~0ull;
+        uint32_t pm = 0;
         if (off < window_bits) {
             const uint64_t w = zi_bits_at(in, nbytes, bit0);
             for (uint32_t s8 = 0; s8 < 8; s8++) {
                 const uint32_t h = (uint32_t)(w >> s8);
                 if ((h & 7u) == 4u && ((h >> 3) & 31u) <= 29u && ((h >> 8) & 31u) <= 29u && off + s8 < window_bits &&
-                    zi_probe_block(in, nbytes, bit0 + s8)) { hit = bit0 + s8; break; }
+                    zi_probe_head(in, nbytes, bit0 + s8)) pm |= 1u << s8;
             }
         }
-        const unsigned long long m = __ballot(hit != ~0ull);
-        if (m) {
-            /* lanes hold increasing positions: the lowest lane with a hit has the first one of this round */
-            if (lane == (uint32_t)(__ffsll((long long)m) - 1)) atomicMin(&s_hit, hit);
-            break;
+        if (__ballot(pm != 0) == 0ull) continue;
+        for (uint32_t s8 = 0; s8 < 8; s8++) {
+            const bool has = (pm >> s8) & 1u;
+            const unsigned long long m = __ballot(has);
+            if (m == 0ull) continue;
+            if (has) q[qn + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = bit0 + s8;
+            qn += (uint32_t)__popcll(m);
+            if (qn >= 64u) drain(64u);
         }
     }
+    if (qn) drain(qn);
     __syncthreads();
     if (threadIdx.x == 0) found[t] = s_hit;
 }
