@@ -238,34 +238,6 @@ def test_parse_driven_matcher_is_exact_too():
     eng.close()
 
 
-def test_four_byte_chain_matcher_is_exact_too():
-    """The search along four-byte chains (k_link4 + k_match4, for chain budgets up to 254): same bytes as the
-    search of every hash-chain member, over texts, zeros, short periods, dictionaries of ragged size and tuned
-    budgets; levels it does not serve fall through to the other search."""
-    import zlib_amd
-    data = O.corpus(3 * 65536 + 77, 4, 91) + O.corpus(150000, 0, 92) + bytes(70000) + O.corpus(100000, 3, 93) + b"abc" * 30000 + O.corpus(90000, 2, 94)
-    os.environ["ZAMD_MATCH_CHAIN4"] = "1"
-    try:
-        eng = zlib_amd.Engine(0)
-    finally:
-        del os.environ["ZAMD_MATCH_CHAIN4"]
-    for level, strategy, chunk in ((4, 0, 131072), (5, 0, 32768), (6, 0, 131072), (6, 1, 65536), (7, 0, 131072), (9, 0, 131072)):
-        out, _ = eng.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk)
-        assert out == O.deflate_chunked(data, chunk, level, strategy, 8)[0], (level, strategy)
-    for tune in ((8, 16, 128, 254), (4, 5, 4, 100), (32, 258, 258, 17)):
-        eng.tune(*tune)
-        chunk = 65536
-        out, _ = eng.deflate_chunks(data[:300000], level=6, chunk_size=chunk)
-        eng.tune()
-        want = b""
-        for c in range((300000 + chunk - 1) // chunk):
-            start = c * chunk
-            dl, ln = min(start, 32768), min(chunk, 300000 - start)
-            want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, 6, 0, 8, start + ln == 300000, tune=tune)
-        assert out == want, tune
-    eng.close()
-
-
 @pytest.mark.parametrize("level,tune", [(6, (4, 64, 8, 128)), (5, (20, 258, 9, 3)), (8, (1, 16, 4, 2)), (6, (33, 1, 8, 2)), (6, (14, 2, 9, 1))])
 def test_tuned_parameters_outside_the_tables_shape(engine, level, tune):
     """nice_length below max_lazy, chain budgets whose quarter is zero, lazy limits below 3."""

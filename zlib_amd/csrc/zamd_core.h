@@ -1,7 +1,7 @@
 /*
  * zamd_core.h — shared per-lane building blocks of the MI355X DEFLATE engine.
  *
- * Everything here is `__host__ __device__`: the HIP kernels in zamd_kernels.hip
+ * Everything here is `__host__ __device__`: the HIP kernels in zamd_engine.hip
  * call these functions from device code, and tests/host_emul.cpp runs the same
  * functions on the host to check the pipeline's decomposition without a GPU.
  *

@@ -2,19 +2,26 @@
  * zamd_engine.hip — HIP kernels (gfx950) and host orchestration of the chunked
  * DEFLATE engine.  C ABI in include/zamd.h; per-lane logic in zamd_core.h.
  *
- * Pipeline for levels 4-9 (one batch of chunks per pass, two batches in flight
- * on two streams):
+ * Pipeline for levels 4-9 (one batch of chunks per pass, up to four batches in
+ * flight on four streams):
  *   k_chain   hash-chain build: INSERT_STRING for every position, head table in
  *             LDS, writes the distance to the previous same-hash string
  *   k_match   longest_match for every position ahead of the parse; window bytes
  *             and chain links of a 16 Ki-position tile (+32 KiB halo) staged in LDS
- *   k_parse   deflate_slow lazy evaluation replayed over the match records in
- *             exact reference order; symbol stream + block table (lit_bufsize rule)
+ *             (k_spec, zamd_spec_impl.h: the search that follows the parse, for
+ *             deflateTune values the precomputed records cannot express)
+ *   k_resolve / k_hop / k_expand
+ *             deflate_slow's lazy evaluation over the match records: per-position
+ *             hop words in parallel, the serial walk over hops, symbol stream and
+ *             block table (lit_bufsize rule) expanded in parallel
+ *             (k_parse: the serial replay, used for Z_RLE / Z_HUFFMAN_ONLY / level 0)
  *   k_plan    per block: _tr_tally histograms with LDS atomics, build_tree x3,
  *             stored/static/dynamic choice, code tables, header bits
  *   k_layout  per chunk bit layout, k_scan exclusive scan -> output offsets
  *   k_emit    compress_block: prefix sums over code lengths, LDS bit staging,
  *             OR into the zeroed output
+ * Levels 1-3: k_fast (zamd_fast_impl.h) replaces chain/match/parse.
+ * Inflate: zamd_inflate_impl.h.
  */
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -45,7 +52,6 @@ struct ZkJob {
     uint32_t prime_bits, prime_val;  /* deflatePrime bits in front of the call's first chunk */
     ZcParams P;
     uint16_t *pdist; uint64_t pdist_base, pdist_len;
-    uint16_t *l4, *f3d; uint8_t *sk, *f3s;   /* four-byte chains (k_link4), indexed like pdist */
     uint2 *rec; uint64_t rec_base;
     uint32_t *sym;
     uint32_t *hop; uint32_t *arr; uint32_t *nhop;
@@ -202,11 +208,8 @@ __device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64
     }
 }
 
-/* MODE 0: the peek is three bytes (best-2..best) out of two aligned LDS dwords; 1: one unaligned dword;
- * 2: the peek is the one aligned dword that holds the candidate's byte best-1, masked to the bytes 0..best;
- * 3 (the default): as 0, with the lanes whose walk has stopped masked off, so that their LDS reads no longer
- * collide with those of the walking lanes (+3 % on the level-6 benchmark, and service can wait for 28 idle lanes) */
-template <int MODE, int THRESH>
+/* Service threshold: a wavefront leaves the candidate loop once this many of its lanes have stopped walking. */
+#define ZK_MATCH_THRESH 28
 __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t tiles_per_chunk, int rle)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_lds[ZK_LDS_BYTES / 4];
@@ -251,16 +254,8 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
      * next service point. */
     const uint32_t nice_match = J.P.nice, max_chain = J.P.chain, qb = max_chain >> 2;
     const uint32_t la0 = (uint32_t)a0;
-    const uint8_t *s_winb = (const uint8_t *)s_win;
     uint32_t p = t0, cur = t0, best = 2, bdist = 0, qrec = 0, scan3 = 0, cap = 0, nice = 0;
-    uint32_t sc1 = 0, msk0 = 0;               /* MODE 2: scan3:sc1 = the bytes best-4..best+3 of the string at p, masked; msk0 = mask of the first four */
-    auto set_scan = [&](uint32_t b) {
-        if (MODE == 2) {
-            msk0 = b >= 4u ? 0xffffffffu : 0xffffffffu << (8u * (4u - b));
-            scan3 = win.load4(p + b - 4u) & msk0;
-            sc1 = win.load4(p + b) & 0xffu;
-        } else scan3 = win.load4(p + b - 2u) & 0x00ffffffu;
-    };
+    auto set_scan = [&](uint32_t b) { scan3 = win.load4(p + b - 2u) & 0x00ffffffu; };
     int32_t kk = 0;                           /* candidates examined minus max_chain: negative while budget remains */
     int32_t walking = 0, parked = 0;          /* sign masks: -1 / 0 */
     uint32_t wcur = 0, wend = 0;              /* this wave's ticket of unclaimed tile positions */
@@ -332,7 +327,6 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 if (zc_match_init(win, pd, t0 + idx, E, g.corner, nice_match, st)) {
                     p = st.p; cur = st.cur; kk = -(int32_t)max_chain; best = 2; bdist = 0; qrec = 0;
                     scan3 = st.scan3; cap = st.cap; nice = st.nice;
-                    if (MODE == 2) set_scan(2u);
                     walking = -1;
                 } else rec[idx] = make_uint2(0u, 0u);
             }
@@ -345,59 +339,22 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         const int32_t lim = (int32_t)(p < ZC_MAX_DIST ? p : ZC_MAX_DIST);      /* stop once the distance reaches this */
         /* the loop runs on ac = candidate + (best - 2) - la0, the LDS byte offset of the candidate's bytes best-2..,
          * so that neither the peek address nor the link address nor the distance test needs an addition of its own */
-        const uint8_t *peek = s_winb;
         const uint32_t peek_off = (best - 2u) - la0;
         const uint16_t *link = s_pd - (best - 2u);   /* link[ac] is the link of the candidate */
         uint32_t c = cur + peek_off;
         const int32_t plim = (int32_t)p - lim + (int32_t)peek_off;   /* the next candidate c' is in reach while plim - c' < 0 */
-        /* a walk that has stopped stays stopped without being told: it looks at the same candidate again (same peek,
-         * same link, same distance) and its count is frozen; lanes that are not walking get a count that says "budget spent" */
+        /* a walk that has stopped is masked off for the rest of the round: c, its count and the last peek result stay as
+         * the stopping step left them; lanes that are not walking get a count that says "budget spent" */
         int32_t wm = walking;
         int32_t kc = kk & walking;
         uint32_t xlast = 1u;
-        if (MODE == 2) {
-            /* the loop variable is n = ~(LDS byte offset of the candidate's byte best-1): its low bits are the byte
-             * shift that lines the scan bytes up with the aligned dword, and distance test and link address are one
-             * instruction each from it */
-            uint32_t n = ~((cur + best - 1u) - la0);
-            const int32_t K = (int32_t)ZK_PD_OFF - 2 * (int32_t)best;
-            const int32_t Kt = (int32_t)p - lim - (int32_t)la0 + (int32_t)best;
-            uint32_t wpos = (uint32_t)walking >> 31;
-            int32_t zlast = 0;
-#pragma unroll 1
-            for (int it = 0; it < 8; it++) {
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const uint32_t W = *(const uint32_t *)(s_winb + ~(n | 3u));
-                    uint32_t la;
-                    asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(la) : "v"(n), "v"(K));      /* K - 2n, written out: the compiler makes two instructions of it */
-                    const int32_t d = (int32_t)*(const uint16_t *)(s_winb + la);
-                    const uint32_t sw = __builtin_amdgcn_alignbyte(sc1, scan3, n), mk = __builtin_amdgcn_alignbyte(0xffu, msk0, n);
-                    /* -1 when every byte that counts is equal, otherwise not negative */
-                    const int32_t z = (int32_t)__builtin_amdgcn_sad_u8((W ^ sw) & mk, 0u, 0xffffffffu);
-                    zlast = z;
-                    kc += (int32_t)wpos;
-                    const int32_t go = ((int32_t)n + d + Kt) & kc & ~z;
-                    wpos = (uint32_t)go >> 31;
-                    asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(n) : "v"(d), "v"(wpos));   /* n += d where the walk continues */
-                }
-                if (__popcll(__ballot(wpos == 0u)) >= THRESH) break;
-            }
-            wm = -(int32_t)wpos;
-            xlast = zlast < 0 ? 0u : 1u;
-            c = (la0 - n - best) + peek_off;
-        } else {
 #pragma unroll 1
         for (int it = 0; it < 64 / ZK_MATCH_STEPS; it++) {
 #pragma unroll
             for (int u = 0; u < ZK_MATCH_STEPS; u++) {
-                if (MODE == 3 && wm >= 0) continue;               /* MODE 3: stopped lanes are masked off, their LDS reads with them */
-                uint32_t v;
-                if (MODE == 1) __builtin_memcpy(&v, peek + c, 4);              /* unaligned LDS dword */
-                else {
-                    const uint32_t wi = c >> 2;
-                    v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], c);   /* the instruction uses bits 1:0 of the shift operand */
-                }
+                if (wm >= 0) continue;                            /* stopped lanes are masked off, their LDS reads with them */
+                const uint32_t wi = c >> 2;
+                const uint32_t v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], c);   /* the instruction uses bits 1:0 of the shift operand */
                 const int32_t d = (int32_t)link[c];
                 const uint32_t x = (v & 0x00ffffffu) ^ scan3;
                 const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
@@ -408,13 +365,12 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 c += (uint32_t)__mul24(d, wm);                    /* one multiply-add: c -= d where the walk continues */
                 asm("" : "+v"(c));                              /* keeps the compiler from deriving the next link address by a multiply of its own */
             }
-            if (__popcll(__ballot(wm == 0)) >= THRESH) break;
-        }
+            if (__popcll(__ballot(wm == 0)) >= ZK_MATCH_THRESH) break;
         }
         if (walking < 0) kk = kc;
         cur = c - peek_off;
-        /* a walk that stopped in this round stands on the candidate that stopped it and has looked at it
-         * again at every step since: it is parked if that candidate passed the peek */
+        /* a walk that stopped in this round stands on the candidate that stopped it: it is parked if that
+         * candidate passed the peek */
         parked = xlast == 0u ? (walking & ~wm) : 0;
         /* a walk that ended without a parked candidate leaves its counters frozen (a lane that is not
          * walking counts nothing): its record is written here, outside the hot loop */
@@ -427,9 +383,6 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     }
 }
 
-#include "zamd_match2_impl.h"
-#include "zamd_match8_impl.h"
-#include "zamd_match4_impl.h"
 #include "zamd_spec_impl.h"
 
 /* ------------------------------------------------------------------ k_parse
@@ -959,7 +912,7 @@ __global__ __launch_bounds__(256) void k_checksum(const uint8_t *in, uint64_t n,
 
 struct ZeWorkspace {
     uint32_t cap_chunks = 0, chunk_size = 0, max_blocks = 0;
-    uint16_t *pdist = nullptr, *l4 = nullptr, *f3d = nullptr; uint8_t *sk = nullptr, *f3s = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr; uint32_t *hop = nullptr; uint32_t *nhop = nullptr;
+    uint16_t *pdist = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr; uint32_t *hop = nullptr; uint32_t *nhop = nullptr;
     ZcBlock *blk = nullptr; ZcBlockTab *tab = nullptr;
     uint32_t *nblk = nullptr, *nsym = nullptr; uint64_t *chunk_bytes = nullptr, *sync_bit = nullptr;
     uint64_t pdist_len = 0;
@@ -976,7 +929,6 @@ struct zamd_engine {
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
     int spec_match;                 /* follow the parse (k_spec) instead of searching every position (k_match) */
-    int chain4_match;               /* search along four-byte chains (k_link4 + k_match4) where the chain budget allows */
     uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
     int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
     uint64_t ws_budget;
@@ -994,7 +946,7 @@ struct zamd_engine {
 
 static void ws_free(ZeWorkspace &w)
 {
-    hipFree(w.pdist); hipFree(w.l4); hipFree(w.f3d); hipFree(w.sk); hipFree(w.f3s); hipFree(w.rec); hipFree(w.sym); hipFree(w.hop); hipFree(w.nhop); hipFree(w.blk); hipFree(w.tab);
+    hipFree(w.pdist); hipFree(w.rec); hipFree(w.sym); hipFree(w.hop); hipFree(w.nhop); hipFree(w.blk); hipFree(w.tab);
     hipFree(w.nblk); hipFree(w.nsym); hipFree(w.chunk_bytes); hipFree(w.sync_bit); hipFree(w.fhead);
     w = ZeWorkspace();
 }
@@ -1043,7 +995,6 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     for (int i = 0; i < ZE_STREAMS; i++) e->ws[i] = ZeWorkspace();
     e->nstreams = 4;                 /* one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4) */
     e->spec_match = getenv("ZAMD_MATCH_SPEC") ? 1 : 0;
-    e->chain4_match = getenv("ZAMD_MATCH_CHAIN4") ? 1 : 0;
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->device = device;
     e->ws_budget = workspace_bytes ? workspace_bytes : (48ull << 30);
@@ -1205,7 +1156,6 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         J.finish = finish; J.P = P; J.prime_bits = prime_bits; J.prime_val = prime_val;
         ZcChunkGeom g0 = zc_geom(J.n, chunk_size, J.chunk0, finish, J.head);
         J.pdist = w.pdist; J.pdist_base = g0.dstart; J.pdist_len = w.pdist_len;
-        J.l4 = w.l4; J.f3d = w.f3d; J.sk = w.sk; J.f3s = w.f3s;
         J.rec = w.rec; J.rec_base = head_dict_len + J.chunk0 * chunk_size;
         J.sym = w.sym; J.hop = w.hop; J.nhop = w.nhop; J.arr = (uint32_t *)w.rec; J.blk = w.blk; J.tab = w.tab; J.nblk = w.nblk; J.nsym = w.nsym;
         J.chunk_bytes = w.chunk_bytes; J.sync_bit = w.sync_bit;
@@ -1224,62 +1174,14 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (P.parser == ZC_PARSE_SLOW && !dense) {
             tm_begin(e, s, 1, &slot);
             HIPCHK(hipMemsetAsync(w.hop, 0, (uint64_t)J.nchunks * chunk_size * 4u, s));
-            static int sv = getenv("ZAMD_SV") ? atoi(getenv("ZAMD_SV")) : 0;
-            dim3 grid(J.nchunks * tiles), blk(ZK_MATCH_THREADS);
-            if (sv == 1) hipLaunchKernelGGL((k_spec<16>), grid, blk, 0, s, J, tiles);
-            else if (sv == 2) hipLaunchKernelGGL((k_spec<44>), grid, blk, 0, s, J, tiles);
-            else hipLaunchKernelGGL((k_spec<32>), grid, blk, 0, s, J, tiles);
+            hipLaunchKernelGGL((k_spec<32>), dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles);
             tm_end(e, s, slot);
         }
         if (dense) {
             tm_begin(e, s, 1, &slot);
             {
-                static int mv = getenv("ZAMD_MV") ? atoi(getenv("ZAMD_MV")) : 0;
-                int rle = P.parser == ZC_PARSE_RLE ? 1 : 0;
-                dim3 grid(J.nchunks * tiles), blk(ZK_MATCH_THREADS);
-                /* optional: budgets that fit the eight-bit step counts of the four-byte chains can search along those */
-                if (!rle && e->chain4_match && P.chain <= ZK4_MAX_CHAIN && P.nice >= 4) {
-                    if (!w.l4) {          /* 6 bytes per position more, only for engines that use this search */
-                        HIPCHK(hipMalloc((void **)&w.l4, w.pdist_len * 2));
-                        HIPCHK(hipMalloc((void **)&w.f3d, w.pdist_len * 2));
-                        HIPCHK(hipMalloc((void **)&w.sk, w.pdist_len));
-                        HIPCHK(hipMalloc((void **)&w.f3s, w.pdist_len));
-                        J.l4 = w.l4; J.f3d = w.f3d; J.sk = w.sk; J.f3s = w.f3s;
-                    }
-                    const uint32_t ltiles = (ZC_WSIZE + chunk_size + ZK_TILE - 1) / ZK_TILE, mtiles = (chunk_size + ZK4_TILE - 1) / ZK4_TILE;
-                    hipLaunchKernelGGL((k_link4<32>), dim3(J.nchunks * ltiles), blk, 0, s, J, ltiles);
-                    tm_end(e, s, slot);
-                    tm_begin(e, s, 10, &slot);
-                    hipLaunchKernelGGL((k_match4<32>), dim3(J.nchunks * mtiles), blk, 0, s, J, mtiles);
-                }
-                else if (mv == 1) hipLaunchKernelGGL((k_match<1, 20>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 2) hipLaunchKernelGGL((k_match<0, 12>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 3) hipLaunchKernelGGL((k_match<0, 44>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 4) hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 5) hipLaunchKernelGGL((k_match<2, 32>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 6) hipLaunchKernelGGL((k_match<2, 20>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv >= 13 && mv <= 15 && !rle) {
-                    const uint32_t t8 = (chunk_size + ZK8_TILE - 1) / ZK8_TILE;
-                    dim3 grid8(J.nchunks * t8);
-                    if (mv == 13) hipLaunchKernelGGL((k_match8<20>), grid8, blk, 0, s, J, t8);
-                    else if (mv == 14) hipLaunchKernelGGL((k_match8<12>), grid8, blk, 0, s, J, t8);
-                    else hipLaunchKernelGGL((k_match8<28>), grid8, blk, 0, s, J, t8);
-                }
-                else if (mv == 10 && !rle) hipLaunchKernelGGL((k_match2<20>), grid, blk, 0, s, J, tiles);
-                else if (mv == 11 && !rle) hipLaunchKernelGGL((k_match2<32>), grid, blk, 0, s, J, tiles);
-                else if (mv == 12 && !rle) hipLaunchKernelGGL((k_match2<12>), grid, blk, 0, s, J, tiles);
-                else if (mv == 16) hipLaunchKernelGGL((k_match<3, 20>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 17) hipLaunchKernelGGL((k_match<3, 28>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 18) hipLaunchKernelGGL((k_match<3, 36>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 19) hipLaunchKernelGGL((k_match<3, 44>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 20) hipLaunchKernelGGL((k_match<3, 52>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 7) hipLaunchKernelGGL((k_match<0, 16>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 8) hipLaunchKernelGGL((k_match<0, 24>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 9) hipLaunchKernelGGL((k_match<0, 32>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 21) hipLaunchKernelGGL((k_match<0, 20>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 22) hipLaunchKernelGGL((k_match<3, 24>), grid, blk, 0, s, J, tiles, rle);
-                else if (mv == 23) hipLaunchKernelGGL((k_match<3, 32>), grid, blk, 0, s, J, tiles, rle);
-                else hipLaunchKernelGGL((k_match<3, 28>), grid, blk, 0, s, J, tiles, rle);
+                const int rle = P.parser == ZC_PARSE_RLE ? 1 : 0;
+                hipLaunchKernelGGL(k_match, dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles, rle);
             }
             tm_end(e, s, slot);
         }
