@@ -130,6 +130,29 @@ int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64_t comp_byt
                            uint32_t chunk_size, const void *d_head_window, void *d_out, uint64_t n_out, int64_t *bad_chunk);
 
 /*
+ * The same in three steps, for ranks that hold consecutive shards of ONE stream and so do not have the window in
+ * front of their shard until the rank before them has produced it (the inflate side of chunk-range sharding; the
+ * reference's counterpart is the window updatewindow() carries from call to call, inflate.c:379-427):
+ *   begin   decodes every chunk and resolves the last 32 KiB of each as far as they depend on this shard alone;
+ *           bytes that come from the window in front of the shard stay references (has_head_window = 0 on the
+ *           shard that starts the stream).  chunk_size >= 32768, n_chunks < 32768.
+ *   tail    d_tail_window (device, 32768 bytes) receives the last 32 KiB of (d_head_window ++ this shard's output):
+ *           the next shard's window, a 32 KiB gather that does not wait for the bulk of the output.
+ *           d_head_window is the previous shard's tail window (ignored when has_head_window was 0).
+ *   finish  completes d_out.
+ * Rank r: begin; receive the window from r-1; tail; send it to r+1; finish.
+ */
+int zamd_inflate_shard_begin_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                                 uint32_t chunk_size, int has_head_window, void *d_out, uint64_t n_out, int64_t *bad_chunk);
+int zamd_inflate_shard_tail_dev(zamd_engine *e, const void *d_head_window, void *d_tail_window);
+int zamd_inflate_shard_finish_dev(zamd_engine *e, const void *d_head_window);
+
+/* Number of batches one deflate call keeps in flight on separate HIP streams (1..8, default 4).  serialize != 0:
+ * the batches are cut the same way but all issued to one stream, so that every kernel runs alone on the GPU, which
+ * is what per-kernel timing needs (zamd_last_timing_ms then returns durations that add up, not overlapping spans). */
+int zamd_engine_set_streams(zamd_engine *e, int nstreams, int serialize);
+
+/*
  * General form: inflate a list of segments of one raw deflate stream, one GPU
  * wavefront per segment.  A segment starts at bit in_bit (a block boundary) and
  * may read up to bit in_end_bit; it decodes whole blocks until the final block,

@@ -189,3 +189,62 @@ def test_sync_marker_search_on_the_gpu(engine):
     stream, offs = engine.deflate_chunks(src, level=6, chunk_size=65536)
     found = set(engine.find_sync(stream))
     assert all(o in found for o in offs[1:-1])
+
+
+@pytest.mark.parametrize("kind,n,chunk,cuts", [(4, 7 * 65536 + 1234, 65536, (3, 5)), (0, 5 * 32768, 32768, (1, 2, 4)),
+                                               (-1, 6 * 65536 + 9, 65536, (2, 4)), (3, 2 * (1 << 20) + 77, 1 << 20, (1,)),
+                                               (-2, 4 * 32768 + 100, 32768, (1, 2, 3))])
+def test_sharded_inflate_hands_the_window_from_shard_to_shard(kind, n, chunk, cuts):
+    """Consecutive shards of one stream on engines of their own, as ranks would hold them: every shard is decoded
+    without the window in front of it (begin), the 32 KiB tail windows go down the line (tail), then the shards
+    complete (finish).  kind -1: zeros, every byte a copy of the one before, so the last window of every shard
+    depends on the first byte of the stream; kind -2: a period of 40 000, longer than the window, ragged end."""
+    import struct
+    if kind == -1:
+        data = bytes(n)
+    elif kind == -2:
+        per = O.corpus(40000, 1, 77)
+        data = (per * (n // 40000 + 1))[:n]
+    else:
+        data = O.corpus(n, kind, 31)
+    e0 = zlib_amd.Engine(0)
+    stream, offs = e0.deflate_chunks(data, level=6, chunk_size=chunk)
+    nchunks = len(offs) - 1
+    bounds = [0] + list(cuts) + [nchunks]
+    engines, bufs, wins = [], [], []
+    try:
+        # begin on every shard before any window exists
+        for r in range(len(bounds) - 1):
+            c0, c1 = bounds[r], bounds[r + 1]
+            e = zlib_amd.Engine(0)
+            comp = stream[offs[c0]:offs[c1]]
+            rel = [o - offs[c0] for o in offs[c0:c1 + 1]]
+            n_out = min(n, c1 * chunk) - c0 * chunk
+            d_comp = e.alloc(len(comp) + 16); d_comp.upload(comp)
+            d_off = e.alloc(8 * len(rel)); d_off.upload(struct.pack("<%dQ" % len(rel), *rel))
+            d_out = e.alloc(max(16, n_out)); d_win_in = e.alloc(32768); d_win_out = e.alloc(32768)
+            e.inflate_shard_begin(d_comp.ptr, len(comp), d_off.ptr, c1 - c0, d_out.ptr, n_out, chunk_size=chunk, has_head=r > 0)
+            engines.append(e); bufs.append((d_comp, d_off, d_out, d_win_in, d_win_out, n_out, c0))
+        # the windows travel
+        prev = None
+        for r, e in enumerate(engines):
+            d_comp, d_off, d_out, d_win_in, d_win_out, n_out, c0 = bufs[r]
+            if r > 0:
+                d_win_in.upload(prev)
+            e.inflate_shard_tail(d_win_in.ptr if r > 0 else 0, d_win_out.ptr)
+            prev = bytes(d_win_out.download(32768))
+            end = c0 * chunk + n_out
+            want = data[max(0, end - 32768):end]
+            assert prev[32768 - len(want):] == want, r
+            wins.append(prev)
+        for r, e in enumerate(engines):
+            d_comp, d_off, d_out, d_win_in, d_win_out, n_out, c0 = bufs[r]
+            e.inflate_shard_finish(d_win_in.ptr if r > 0 else 0)
+            assert bytes(d_out.download(n_out)) == data[c0 * chunk:c0 * chunk + n_out], r
+    finally:
+        for b in bufs:
+            for d in b[:5]:
+                d.free()
+        for e in engines:
+            e.close()
+        e0.close()

@@ -79,6 +79,14 @@ def load_library() -> C.CDLL:
     lib.zamd_inflate_dev.restype = i32
     lib.zamd_inflate_shard_dev.argtypes = [vp, vp, u64, vp, u64, u32, vp, vp, u64, C.POINTER(C.c_int64)]
     lib.zamd_inflate_shard_dev.restype = i32
+    lib.zamd_inflate_shard_begin_dev.argtypes = [vp, vp, u64, vp, u64, u32, i32, vp, u64, C.POINTER(C.c_int64)]
+    lib.zamd_inflate_shard_begin_dev.restype = i32
+    lib.zamd_inflate_shard_tail_dev.argtypes = [vp, vp, vp]
+    lib.zamd_inflate_shard_tail_dev.restype = i32
+    lib.zamd_inflate_shard_finish_dev.argtypes = [vp, vp]
+    lib.zamd_inflate_shard_finish_dev.restype = i32
+    lib.zamd_engine_set_streams.argtypes = [vp, i32, i32]
+    lib.zamd_engine_set_streams.restype = i32
     lib.zamd_inflate_segments_dev.argtypes = [vp, vp, u64, C.POINTER(InflateSeg), u64, vp, vp, u64]
     lib.zamd_inflate_segments_dev.restype = i32
     lib.zamd_inflate_message.argtypes = [u32]
@@ -296,6 +304,27 @@ class Engine:
         if rc == Z_DATA_ERROR:
             raise self._inflate_error(rc, "zamd_inflate_dev")
         _chk(rc, "zamd_inflate_dev")
+
+    def set_streams(self, nstreams: int = 4, serialize: bool = False) -> None:
+        """Batches a deflate call keeps in flight; serialize: same batches on one stream (per-kernel timing)."""
+        _chk(self.lib.zamd_engine_set_streams(self.handle, nstreams, int(serialize)), "zamd_engine_set_streams")
+
+    def inflate_shard_begin(self, d_comp: int, comp_bytes: int, d_chunk_off: int, n_chunks: int, d_out: int, n_out: int, *,
+                            chunk_size: int = 1 << 20, has_head: bool = False) -> None:
+        """First step of the sharded inflate: decode without the window in front of the shard."""
+        bad = C.c_int64(-1)
+        rc = self.lib.zamd_inflate_shard_begin_dev(self.handle, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size,
+                                                   int(has_head), d_out, n_out, C.byref(bad))
+        if rc == Z_DATA_ERROR:
+            raise self._inflate_error(rc, "zamd_inflate_shard_begin_dev")
+        _chk(rc, "zamd_inflate_shard_begin_dev")
+
+    def inflate_shard_tail(self, d_head_window: int, d_tail_window: int) -> None:
+        """Second step: this shard's last 32 KiB (the next shard's window) from the window in front of it."""
+        _chk(self.lib.zamd_inflate_shard_tail_dev(self.handle, d_head_window or None, d_tail_window), "zamd_inflate_shard_tail_dev")
+
+    def inflate_shard_finish(self, d_head_window: int) -> None:
+        _chk(self.lib.zamd_inflate_shard_finish_dev(self.handle, d_head_window or None), "zamd_inflate_shard_finish_dev")
 
     def inflate_chunks(self, stream, offsets, n_out: int, *, chunk_size: int = 1 << 20, head_window=None) -> bytes:
         """Host convenience around inflate_dev: offsets = chunk offsets + total, as deflate_chunks returns."""

@@ -928,6 +928,7 @@ struct zamd_engine {
     hipEvent_t ev_scan[ZE_STREAMS], ev_init;
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
+    int serialize;                  /* batches are cut as for nstreams in flight but issued to one stream: every kernel alone on the GPU */
     int spec_match;                 /* follow the parse (k_spec) instead of searching every position (k_match) */
     uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
     int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
@@ -996,6 +997,7 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     e->nstreams = 4;                 /* one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4) */
     e->spec_match = getenv("ZAMD_MATCH_SPEC") ? 1 : 0;
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
+    e->serialize = getenv("ZAMD_SERIALIZE") ? 1 : 0;
     e->device = device;
     e->ws_budget = workspace_bytes ? workspace_bytes : (48ull << 30);
     for (int i = 0; i < ZE_STREAMS; i++) {
@@ -1045,6 +1047,13 @@ extern "C" int zamd_engine_tune(zamd_engine *e, int good_length, int max_lazy, i
         return ZAMD_STREAM_ERROR;
     e->tune[0] = (uint32_t)good_length; e->tune[1] = (uint32_t)max_lazy; e->tune[2] = (uint32_t)nice_length; e->tune[3] = (uint32_t)max_chain;
     e->tuned = 1;
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_engine_set_streams(zamd_engine *e, int nstreams, int serialize)
+{
+    if (!e || nstreams < 1 || nstreams > ZE_STREAMS) return ZAMD_STREAM_ERROR;
+    e->nstreams = nstreams; e->serialize = serialize ? 1 : 0;
     return ZAMD_OK;
 }
 
@@ -1147,8 +1156,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     HIPCHK(hipEventRecord(e->ev_scan[NS - 1], s0));     /* batch 0's predecessor "scan" */
     const uint32_t tiles = (chunk_size + ZK_TILE - 1) / ZK_TILE;
     for (uint32_t bi = 0; bi < nbatches; bi++) {
-        const int si = (int)(bi % (uint32_t)NS);
-        hipStream_t s = e->st[si];
+        const int si = (int)(bi % (uint32_t)NS);                /* workspace and scan-event slot */
+        hipStream_t s = e->st[e->serialize ? 0 : si];
         ZeWorkspace &w = e->ws[si];
         ZkJob J; memset(&J, 0, sizeof J);
         J.in = (const uint8_t *)d_in - head_dict_len; J.n = n + head_dict_len; J.head = head_dict_len; J.chunk0 = (uint64_t)bi * batch;

@@ -675,6 +675,10 @@ __global__ __launch_bounds__(1024) void k_inf_tail_serial(const ZiSeg *segs, uin
  * points at, so chains that run back through s segments vanish in log2(s) rounds.
  * In-place updates are safe: a slot always holds either its byte or a pointer
  * to a slot that will hold the same byte. */
+/* head == nullptr: the window in front of the first segment is not known yet (it is another rank's output): its
+ * bytes stay references, bit 30 | index into that window, which the jump rounds treat as resolved. */
+#define ZI_REF_BYTE 0x80000000u
+#define ZI_REF_HEAD 0x40000000u
 __global__ __launch_bounds__(1024) void k_inf_ref_init(const ZiSeg *segs, const uint16_t *out16, const uint8_t *head, uint32_t *ref)
 {
     const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
@@ -684,7 +688,7 @@ __global__ __launch_bounds__(1024) void k_inf_ref_init(const ZiSeg *segs, const 
     const uint32_t v = out16[S.out_off + S.out_len - tl + e];
     uint32_t r;
     if (v < ZI_MARK) r = 0x80000000u | v;
-    else if (si == 0) r = 0x80000000u | head[v - ZI_MARK];
+    else if (si == 0) r = head ? (ZI_REF_BYTE | head[v - ZI_MARK]) : (ZI_REF_HEAD | (v - ZI_MARK));
     else r = (si - 1u) * 32768u + (v - ZI_MARK);
     ref[(uint64_t)si * 32768u + e] = r;
 }
@@ -693,15 +697,36 @@ __global__ __launch_bounds__(256) void k_inf_ref_jump(uint32_t *ref, uint64_t n)
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = ref[i];
-    if (!(r >> 31)) ref[i] = __hip_atomic_load(ref + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(r >> 30)) ref[i] = __hip_atomic_load(ref + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(1024) void k_inf_ref_write(const ZiSeg *segs, const uint32_t *ref, uint8_t *out8)
+__global__ __launch_bounds__(1024) void k_inf_ref_write(const ZiSeg *segs, const uint32_t *ref, uint8_t *out8, const uint8_t *head)
 {
     const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
     const ZiSeg S = segs[si];
     const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
     if (e >= tl) return;
-    out8[S.out_off + S.out_len - tl + e] = (uint8_t)ref[(uint64_t)si * 32768u + e];
+    const uint32_t r = ref[(uint64_t)si * 32768u + e];
+    out8[S.out_off + S.out_len - tl + e] = (r & ZI_REF_HEAD) ? head[r & 32767u] : (uint8_t)r;
+}
+/* The last 32 KiB of (window in front of the shard ++ the shard's output) from the jumped references: what the
+ * rank that holds the next shard needs as ITS window, long before the bulk of this shard's output is resolved. */
+__global__ __launch_bounds__(1024) void k_inf_tail_window(const ZiSeg *segs, uint64_t nseg, const uint32_t *ref, const uint8_t *head,
+                                                          uint64_t n_out, uint8_t *win)
+{
+    const uint32_t j = blockIdx.x * 1024u + threadIdx.x;
+    if (j >= 32768u) return;
+    const int64_t pos = (int64_t)n_out - 32768 + (int64_t)j;
+    uint8_t b = 0;
+    if (pos < 0) b = head ? head[32768 + pos] : (uint8_t)0;
+    else {
+        uint64_t si = nseg - 1;
+        if (si > 0 && (uint64_t)pos < segs[si].out_off) si--;
+        const ZiSeg S = segs[si];
+        const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
+        const uint32_t r = ref[si * 32768u + ((uint64_t)pos - (S.out_off + S.out_len - tl))];
+        b = (r & ZI_REF_HEAD) ? (head ? head[r & 32767u] : (uint8_t)0) : (uint8_t)r;
+    }
+    win[j] = b;
 }
 
 /* Everything in front of the tails: 8 elements per thread. */
@@ -754,6 +779,8 @@ struct ZiState {
     unsigned long long *d_res = nullptr;
     uint32_t last_status = 0; int64_t last_seg = -1;
     uint64_t *d_scan = nullptr; uint32_t scan_cap = 0;          /* zamd_find_sync_dev's result list */
+    /* a sharded inflate between its begin and finish calls */
+    bool pending = false; bool pend_has_head = false; uint64_t pend_nseg = 0, pend_out_bytes = 0; uint32_t pend_chunk = 0; void *pend_out = nullptr;
 };
 
 static void zi_free(zamd_engine *e)
@@ -791,8 +818,9 @@ static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems, bool r
 }
 
 /* decode (+ resolve when d_out != NULL) the segments already in z->d_segs */
+static int zi_finish(zamd_engine *e, const void *d_head);
 static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint64_t nseg, uint32_t chunk_size,
-                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg, bool regular_tails)
+                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg, bool regular_tails, bool defer = false)
 {
     ZiState *z = e->inf;
     hipStream_t s = e->st[0];
@@ -818,15 +846,23 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
     }
     if (d_out && rc == ZAMD_OK && out_bytes) {
         tm_begin(e, s, 8, &slot);
-        if (regular_tails && nseg < 65536 && !getenv("ZAMD_INF_SERIAL_TAILS")) {
+        if (regular_tails && nseg < 32768 && (defer || !getenv("ZAMD_INF_SERIAL_TAILS"))) {
             const uint64_t nref = nseg * 32768ull;
-            hipLaunchKernelGGL(k_inf_ref_init, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (const uint8_t *)d_head, z->d_mlist);
+            hipLaunchKernelGGL(k_inf_ref_init, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, defer ? (const uint8_t *)nullptr : (const uint8_t *)d_head, z->d_mlist);
             uint32_t rounds = 1;
             while ((1ull << rounds) < nseg) rounds++;
             for (uint32_t r = 0; r <= rounds; r++)
                 hipLaunchKernelGGL(k_inf_ref_jump, dim3((uint32_t)((nref + 255) / 256)), dim3(256), 0, s, z->d_mlist, nref);
-            hipLaunchKernelGGL(k_inf_ref_write, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, (uint8_t *)d_out);
+            if (defer) {
+                tm_end(e, s, slot);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(s));
+                z->pending = true; z->pend_nseg = nseg; z->pend_out_bytes = out_bytes; z->pend_chunk = chunk_size; z->pend_out = d_out;
+                return ZAMD_OK;
+            }
+            hipLaunchKernelGGL(k_inf_ref_write, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, (uint8_t *)d_out, (const uint8_t *)d_head);
         } else {
+            if (defer) return ZAMD_STREAM_ERROR;
             HIPCHK(hipMemsetAsync(z->d_marks, 0, nseg * 4, s));
             hipLaunchKernelGGL(k_inf_tail_pre, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (uint8_t *)d_out, z->d_marks, z->d_mlist);
             hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, (uint8_t *)d_out, z->d_marks, z->d_mlist, (const uint8_t *)d_head);
@@ -856,6 +892,63 @@ extern "C" int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64
                        d_head_window ? 32768u : 0u, e->inf->d_segs);
     if (getenv("ZAMD_INF_COUNTONLY")) d_out = nullptr;      /* diagnostic: decode without writing */
     return zi_run(e, d_comp, comp_bytes, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk, chunk_size >= 32768);
+}
+
+/* Second half of a deferred zi_run: the window in front of the shard has arrived. */
+static int zi_finish(zamd_engine *e, const void *d_head)
+{
+    ZiState *z = e->inf;
+    hipStream_t s = e->st[0];
+    const uint64_t nseg = z->pend_nseg;
+    int slot;
+    tm_begin(e, s, 8, &slot);
+    hipLaunchKernelGGL(k_inf_ref_write, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, (uint8_t *)z->pend_out, (const uint8_t *)d_head);
+    const uint64_t groups = (z->pend_out_bytes + 2047) / 2048;
+    hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, z->pend_chunk, z->d_stage, (uint8_t *)z->pend_out, (const uint8_t *)d_head, z->pend_out_bytes);
+    tm_end(e, s, slot);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    z->pending = false;
+    for (int k2 = 0; k2 < 12; k2++) { e->t_ms[k2] = 0; e->t_n[k2] = 0; }
+    for (int i = 0; i < e->n_tm; i++) { float ms = 0; if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->t_ms[e->tm[i].which] += ms; e->t_n[e->tm[i].which]++; } }
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_inflate_shard_begin_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                                            uint32_t chunk_size, int has_head_window, void *d_out, uint64_t n_out, int64_t *bad_chunk)
+{
+    if (!e || !d_comp || !d_chunk_off || !d_out || chunk_size < 32768 || (chunk_size & 7u)) return ZAMD_STREAM_ERROR;
+    if (((uintptr_t)d_comp & 3u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
+    if (n_chunks == 0 || n_chunks >= 32768 || n_out == 0) return ZAMD_STREAM_ERROR;
+    if ((n_out + chunk_size - 1) / chunk_size != n_chunks) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    int rc = zi_ensure(e, n_chunks, n_chunks * (uint64_t)chunk_size, true);
+    if (rc) return rc;
+    e->inf->pending = false; e->inf->pend_has_head = has_head_window != 0;
+    hipLaunchKernelGGL(k_inf_setup, dim3((uint32_t)((n_chunks + 255) / 256)), dim3(256), 0, e->st[0], d_chunk_off, n_chunks, chunk_size, n_out,
+                       has_head_window ? 32768u : 0u, e->inf->d_segs);
+    return zi_run(e, d_comp, comp_bytes, n_chunks, chunk_size, nullptr, d_out, n_out, bad_chunk, true, true);
+}
+
+extern "C" int zamd_inflate_shard_tail_dev(zamd_engine *e, const void *d_head_window, void *d_tail_window)
+{
+    if (!e || !e->inf || !e->inf->pending || !d_tail_window) return ZAMD_STREAM_ERROR;
+    ZiState *z = e->inf;
+    if (z->pend_has_head && !d_head_window) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_inf_tail_window, dim3(32), dim3(1024), 0, e->st[0], z->d_segs, z->pend_nseg, z->d_mlist,
+                       z->pend_has_head ? (const uint8_t *)d_head_window : (const uint8_t *)nullptr, z->pend_out_bytes, (uint8_t *)d_tail_window);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->st[0]));
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_inflate_shard_finish_dev(zamd_engine *e, const void *d_head_window)
+{
+    if (!e || !e->inf || !e->inf->pending) return ZAMD_STREAM_ERROR;
+    if (e->inf->pend_has_head && !d_head_window) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    return zi_finish(e, e->inf->pend_has_head ? d_head_window : nullptr);
 }
 
 extern "C" int zamd_inflate_dev(zamd_engine *e, const void *d_comp, const uint64_t *d_chunk_off, uint64_t n_chunks,

@@ -4,7 +4,9 @@ Chunks are independent given the input, so rank r takes the contiguous range
 ``shard_chunks(n_chunks, r, world)`` plus a 32 KiB input halo.  The one exchange
 step of the path is an all-gather of per-chunk compressed lengths (RCCL on GPUs,
 gloo in the CPU tests) followed by an exclusive scan that places every chunk in
-the global output."""
+the global output.  Inflate shards the same way; there the window in front of a
+shard is the previous rank's last 32 KiB of OUTPUT, handed from rank to rank
+point to point (``inflate_shard_handover``)."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -37,3 +39,23 @@ def gather_offsets(local_lens: torch.Tensor, n_chunks: int, rank: int, world: in
     excl = csum - all_lens
     c0, c1 = shard_chunks(n_chunks, rank, world)
     return excl[c0:c1], int(csum[-1].item()) if csum.numel() else 0
+
+
+def inflate_shard_handover(engine, rank: int, world: int, win_in: torch.Tensor, win_out: torch.Tensor, *begin_args, **begin_kw) -> None:
+    """Sharded inflate of consecutive shards of one stream, one shard per rank.
+
+    ``engine`` has the three steps of include/zamd.h (``inflate_shard_begin`` /
+    ``inflate_shard_tail`` / ``inflate_shard_finish``); ``win_in`` / ``win_out`` are
+    32768-byte uint8 tensors (device tensors with RCCL, CPU tensors with gloo).
+    Every rank decodes at once; only the 32 KiB tail windows travel, rank r -> r+1,
+    each a gather over the window that arrived, so the chain costs world-1 small
+    sends and not world-1 decodes."""
+    engine.inflate_shard_begin(*begin_args, has_head=rank > 0, **begin_kw)
+    if rank > 0:
+        dist.recv(win_in, src=rank - 1)
+        if win_in.is_cuda:          # the engine works on streams of its own: the received bytes must have landed
+            torch.cuda.current_stream().synchronize()
+    if rank + 1 < world:
+        engine.inflate_shard_tail(win_in.data_ptr() if rank > 0 else 0, win_out.data_ptr())
+        dist.send(win_out, dst=rank + 1)
+    engine.inflate_shard_finish(win_in.data_ptr() if rank > 0 else 0)
