@@ -85,6 +85,26 @@ int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_
  * matcher that follows the parse; the output stays the reference's. */
 int zamd_engine_tune(zamd_engine *e, int good_length, int max_lazy, int nice_length, int max_chain);
 
+/* windowBits of the following deflate calls of this engine: 9..15, default 15 (deflate.c:271-291: w_size = 1 << windowBits,
+ * MAX_DIST = w_size - 262; a chunk's dictionary is then the previous w_size bytes, and head_dict_len at most w_size). */
+int zamd_engine_window_bits(zamd_engine *e, int window_bits);
+
+/* How the next deflate call of this engine (only) ends when finish == 0: what deflate() does after its last block for
+ * Z_SYNC_FLUSH / Z_FULL_FLUSH (0: the empty stored block 00 00 FF FF, deflate.c:926-927), Z_PARTIAL_FLUSH (1: _tr_align,
+ * an empty static block of 10 bits, trees.c:892-901) or Z_BLOCK (2: nothing, deflate.c:923-925).  Chunks inside the call
+ * still end on sync markers.  With 1 and 2 the output can end inside a byte: *total_out counts the complete bytes and
+ * zamd_engine_pending_bits returns the bits (fewer than 8) behind them, which the reference keeps in its bit buffer
+ * (deflatePending, deflate.c:450-461); hand them to the next call with zamd_engine_prime. */
+#define ZAMD_TAIL_SYNC  0
+#define ZAMD_TAIL_ALIGN 1
+#define ZAMD_TAIL_NONE  2
+int zamd_engine_tail(zamd_engine *e, int mode);
+int zamd_engine_pending_bits(zamd_engine *e, int *bits, int *value);
+
+/* strm->data_type as the last deflate call would have set it (trees.c:920-921, 1120-1147: detect_data_type on the
+ * literal counts of the first block at level > 0): 0 Z_BINARY, 1 Z_TEXT, 2 Z_UNKNOWN (no block, or level 0). */
+int zamd_engine_data_type(zamd_engine *e);
+
 /* deflatePrime (deflate.c:464-487) for the next deflate call of this engine only: `bits`
  * (0..7) low bits of `value` precede the first block of the call's first chunk, which
  * starts inside output byte 0 as it does in the reference after deflatePrime. */

@@ -64,6 +64,30 @@ static void kat(const char *name, const uint8_t *in, size_t n, int level, int st
     printf("\"}");
 }
 
+/* One chunk with a dictionary of any length, any windowBits and any flush value: the reference's bytes, the bits it
+ * keeps in its bit buffer afterwards (deflatePending) and strm->data_type. */
+static void boundary_row(int kind, uint64_t seed, size_t n, size_t dict, int level, int strat, int wbits, int flush)
+{
+    uint8_t *buf = malloc(dict + n + 1), *out = malloc(n + n / 4 + 65536);
+    zo_corpus_fill(buf, dict, kind, seed + 1000);
+    zo_corpus_fill(buf + dict, n, kind, seed);
+    z_stream z; memset(&z, 0, sizeof z);
+    if (deflateInit2(&z, level, Z_DEFLATED, -wbits, 8, strat) != Z_OK) exit(5);
+    if (dict && deflateSetDictionary(&z, buf, (uInt)dict) != Z_OK) exit(6);
+    z.next_in = buf + dict; z.avail_in = (uInt)n; z.next_out = out; z.avail_out = (uInt)(n + n / 4 + 65536);
+    int r = deflate(&z, flush);
+    if (r != (flush == Z_FINISH ? Z_STREAM_END : Z_OK) || z.avail_in) exit(7);
+    size_t res = z.total_out; unsigned pend = 0; int bits = 0, val = 0, dt = z.data_type;
+    deflatePending(&z, &pend, &bits);
+    if (bits) { Bytef extra[16]; z.next_out = extra; z.avail_out = sizeof extra; if (deflate(&z, Z_FINISH) != Z_STREAM_END) exit(8); val = extra[0] & ((1 << bits) - 1); }
+    deflateEnd(&z);
+    printf("%s  {\"kind\": %d, \"seed\": %llu, \"n\": %zu, \"dict\": %zu, \"level\": %d, \"strategy\": %d, \"wbits\": %d, \"flush\": %d, "
+           "\"out_len\": %zu, \"out_crc\": \"%08lx\", \"pend_bits\": %d, \"pend_val\": %d, \"data_type\": %d}",
+           first ? "" : ",\n", kind, (unsigned long long)seed, n, dict, level, strat, wbits, flush, res, crc32(0, out, (uInt)res), bits, val, dt);
+    first = 0;
+    free(buf); free(out);
+}
+
 int main(void)
 {
     const size_t N = 4u * 1048576u + 12345u, C = 1048576u;
@@ -94,6 +118,21 @@ int main(void)
     for (int i = 0; i < 3000; i++) { b[2 * i] = 'a'; b[2 * i + 1] = 'b'; } b[6000] = 'c'; kat("ab3000c", b, 6001, 9, 0);
     memset(b, 'a', 40); kat("a40_rle", b, 40, 6, 3);
     memcpy(b, "abababababab", 12); memset(b + 12, 'z', 300); kat("ab6z300_rle", b, 312, 6, 3);
+    /* the boundary cases of the stream API: dictionaries of any length, windowBits 9..14, every flush value, data_type */
+    printf("\n],\n\"boundary\": [\n"); first = 1;
+    { static const size_t dl[] = {1, 2, 3, 15, 17, 1001, 32767, 32768};
+      for (int i = 0; i < 8; i++) { boundary_row(0, 11, 200000, dl[i], 6, 0, 15, Z_SYNC_FLUSH); boundary_row(4, 12, 150001, dl[i], 1, 0, 15, Z_FINISH); }
+      boundary_row(3, 13, 100000, 50, 9, 1, 15, Z_SYNC_FLUSH); boundary_row(2, 14, 90000, 777, 6, 3, 15, Z_SYNC_FLUSH); boundary_row(0, 15, 70000, 4097, 4, 4, 15, Z_FINISH); }
+    for (int w = 9; w <= 14; w++) {
+        boundary_row(0, 20 + w, 300000, (size_t)1 << w, 6, 0, w, Z_SYNC_FLUSH); boundary_row(4, 30 + w, 200000, 0, 9, 0, w, Z_FINISH);
+        boundary_row(3, 40 + w, 150000, ((size_t)1 << w) - 5, 1, 0, w, Z_SYNC_FLUSH); boundary_row(2, 50 + w, 100000, 100, 3, 0, w, Z_FINISH);
+        boundary_row(0, 60 + w, 80000, (size_t)1 << w, 6, 3, w, Z_SYNC_FLUSH); boundary_row(4, 70 + w, 65536 + 300, (size_t)1 << w, 0, 0, w, Z_SYNC_FLUSH);
+    }
+    { static const int fl[] = {Z_PARTIAL_FLUSH, Z_BLOCK, Z_FULL_FLUSH};
+      for (int f = 0; f < 3; f++) for (int k = 0; k < 5; k++) {
+          boundary_row(k, 80 + k, 100000 + 7 * k, k & 1 ? 32768 : 0, k == 2 ? 1 : 6, 0, 15, fl[f]);
+          boundary_row(k, 90 + k, 3 * k, 0, 6, 0, 15, fl[f]); } }
+    for (int k = 0; k < 5; k++) { boundary_row(k, 100 + k, 50000, 0, 6, 0, 15, Z_FINISH); boundary_row(k, 110 + k, 50000, 0, 0, 0, 15, Z_FINISH); boundary_row(k, 120 + k, 40000, 0, 6, 2, 15, Z_FINISH); }
     printf("\n]}\n");
     return 0;
 }

@@ -117,6 +117,7 @@ typedef struct {
     uint64_t opt_len, static_len;
     uint8_t *out; size_t out_cap, out_n; uint64_t bitbuf; int bitcnt; int overflow;
     uint64_t bits_total;
+    int data_type;                           /* strm->data_type: 2 = Z_UNKNOWN until the first block at level > 0 */
     zo_trace *tr; size_t tr_sym_base;
 } enc_t;
 
@@ -312,6 +313,17 @@ static void flush_block(enc_t *s, uint32_t p, int last)
     int max_bl = 2;
     uint64_t opt_lenb, static_lenb;
     if (s->level > 0) {
+        if (s->data_type == 2) {                    /* detect_data_type(), trees.c:920-921, 1120-1147 */
+            unsigned long black_mask = 0xf3ffc07fUL; int n;
+            s->data_type = -1;
+            for (n = 0; n <= 31; n++, black_mask >>= 1)
+                if ((black_mask & 1) && s->lt.freq[n] != 0) { s->data_type = 0; break; }
+            if (s->data_type < 0) {
+                if (s->lt.freq[9] != 0 || s->lt.freq[10] != 0 || s->lt.freq[13] != 0) s->data_type = 1;
+                else for (n = 32; n < 256; n++) if (s->lt.freq[n] != 0) { s->data_type = 1; break; }
+            }
+            if (s->data_type < 0) s->data_type = 0;
+        }
         make_tree(s, &s->lt, &L_DESC);
         make_tree(s, &s->dt, &D_DESC);
         /* build_bl_tree(): trees.c:801-829 */
@@ -554,6 +566,21 @@ size_t zo_deflate_chunk_primed(const uint8_t *buf, size_t dict_len, size_t n,
                                int final, const int *tune, int prime_bits, int prime_val,
                                uint8_t *out, size_t out_cap, zo_trace *trace)
 {
+    return zo_deflate_chunk_ex(buf, dict_len, n, level, strategy, mem_level, wbits, final ? ZO_FLUSH_FINISH : ZO_FLUSH_SYNC,
+                               tune, prime_bits, prime_val, out, out_cap, trace, NULL, NULL, NULL);
+}
+
+/* the general form: `flush` is what the one deflate() call is given (deflate.c:923-945); with Z_PARTIAL_FLUSH and
+ * Z_BLOCK the stream can end inside a byte: the return value counts the whole bytes (what deflate() hands out) and
+ * pend_bits / pend_val the bits left in the bit buffer (what deflatePending() reports, deflate.c:450-461) */
+size_t zo_deflate_chunk_ex(const uint8_t *buf, size_t dict_len, size_t n,
+                           int level, int strategy, int mem_level, int wbits,
+                           int flush, const int *tune, int prime_bits, int prime_val,
+                           uint8_t *out, size_t out_cap, zo_trace *trace,
+                           int *pend_bits, int *pend_val, int *data_type)
+{
+    const int final = flush == ZO_FLUSH_FINISH;
+    if (flush < 0 || flush > 3) return (size_t)-1;
     if (prime_bits < 0 || prime_bits > 7) return (size_t)-1;
     if (level == -1) level = 6;                                    /* deflate.c:258 */
     if (level < 0 || level > 9 || strategy < 0 || strategy > 4 || mem_level < 1 || mem_level > 9 ||
@@ -574,7 +601,7 @@ size_t zo_deflate_chunk_primed(const uint8_t *buf, size_t dict_len, size_t n,
     s->d_buf = (uint16_t *)malloc(s->lit_bufsize * sizeof(uint16_t));
     s->l_buf = (uint8_t *)malloc(s->lit_bufsize);
     s->p_buf = (uint32_t *)malloc(s->lit_bufsize * sizeof(uint32_t));
-    s->out = out; s->out_cap = out_cap; s->tr = trace;
+    s->out = out; s->out_cap = out_cap; s->tr = trace; s->data_type = 2;
     if (trace) s->tr_sym_base = trace->n_syms;
     reset_block(s);
     if (prime_bits) put_bits(s, (unsigned)prime_val & ((1u << prime_bits) - 1u), prime_bits);
@@ -597,9 +624,17 @@ size_t zo_deflate_chunk_primed(const uint8_t *buf, size_t dict_len, size_t n,
     if (final) flush_block(s, p, 1);
     else {
         if (s->last_lit || (s->level == 0 && p > s->block_start)) flush_block(s, p, 0);   /* deflate.c:1616, 1720, 1850 */
-        /* Z_SYNC_FLUSH: empty stored block, deflate.c:926-927, trees.c:865-877 */
-        put_bits(s, 0, 3); byte_align(s); put_bits(s, 0x0000, 16); put_bits(s, 0xffff, 16);
+        if (flush == ZO_FLUSH_SYNC) {
+            /* Z_SYNC_FLUSH: empty stored block, deflate.c:926-927, trees.c:865-877 */
+            put_bits(s, 0, 3); byte_align(s); put_bits(s, 0x0000, 16); put_bits(s, 0xffff, 16);
+        } else if (flush == ZO_FLUSH_PARTIAL) {
+            /* Z_PARTIAL_FLUSH: _tr_align, trees.c:892-901: an empty static block, then bi_flush (whole bytes only) */
+            put_bits(s, 1 << 1, 3); put_bits(s, st_lcode[END_BLOCK], st_llen[END_BLOCK]);
+        }                                           /* Z_BLOCK: nothing more, deflate.c:923-925 */
     }
+    if (pend_bits) *pend_bits = s->bitcnt;
+    if (pend_val) *pend_val = (int)(s->bitbuf & ((1u << s->bitcnt) - 1u));
+    if (data_type) *data_type = s->data_type;
     size_t res = s->overflow ? (size_t)-1 : s->out_n;
     free(s->head); free(s->prev); free(s->d_buf); free(s->l_buf); free(s->p_buf); free(s);
     return res;
@@ -610,12 +645,22 @@ size_t zo_deflate_chunked(const uint8_t *in, size_t n, size_t chunk_size,
                           uint8_t *out, size_t out_cap,
                           uint32_t *chunk_len, size_t max_chunks)
 {
+    return zo_deflate_chunked_w(in, n, chunk_size, level, strategy, mem_level, 15, out, out_cap, chunk_len, max_chunks);
+}
+
+size_t zo_deflate_chunked_w(const uint8_t *in, size_t n, size_t chunk_size,
+                            int level, int strategy, int mem_level, int wbits,
+                            uint8_t *out, size_t out_cap,
+                            uint32_t *chunk_len, size_t max_chunks)
+{
     size_t off = 0, o = 0, c = 0;
+    if (wbits < 9 || wbits > 15) return (size_t)-1;
+    const size_t wsize = (size_t)1 << wbits;
     do {
         size_t len = n - off < chunk_size ? n - off : chunk_size;
-        size_t dict = off < 32768 ? off : 32768;
+        size_t dict = off < wsize ? off : wsize;
         int final = off + len >= n;
-        size_t r = zo_deflate_chunk(in + off - dict, dict, len, level, strategy, mem_level, 15,
+        size_t r = zo_deflate_chunk(in + off - dict, dict, len, level, strategy, mem_level, wbits,
                                     final, out + o, out_cap - o, NULL);
         if (r == (size_t)-1 || c >= max_chunks) return (size_t)-1;
         chunk_len[c++] = (uint32_t)r; o += r; off += len;

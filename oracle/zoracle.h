@@ -72,6 +72,16 @@ size_t zo_deflate_chunk_primed(const uint8_t *buf, size_t dict_len, size_t n,
 size_t zo_deflate_chunk(const uint8_t *buf, size_t dict_len, size_t n,
                         int level, int strategy, int mem_level, int wbits,
                         int final, uint8_t *out, size_t out_cap, zo_trace *trace);
+/* ... and the general form: `flush` is the flush value of the one deflate() call (deflate.c:923-945).  Z_PARTIAL_FLUSH
+ * (_tr_align, trees.c:892-901) and Z_BLOCK can end inside a byte: the return value counts whole bytes, *pend_bits /
+ * *pend_val the bits left in the bit buffer (deflatePending, deflate.c:450-461), *data_type what strm->data_type is
+ * afterwards (trees.c:920-921, 1120-1147; 2 = Z_UNKNOWN).  The three result pointers may be NULL. */
+enum { ZO_FLUSH_SYNC = 0, ZO_FLUSH_FINISH = 1, ZO_FLUSH_PARTIAL = 2, ZO_FLUSH_BLOCK = 3 };
+size_t zo_deflate_chunk_ex(const uint8_t *buf, size_t dict_len, size_t n,
+                           int level, int strategy, int mem_level, int wbits,
+                           int flush, const int *tune, int prime_bits, int prime_val,
+                           uint8_t *out, size_t out_cap, zo_trace *trace,
+                           int *pend_bits, int *pend_val, int *data_type);
 
 /* Whole-buffer chunked compression (the recipe of the accelerated path):
  * chunk i is primed with the previous min(32768, offset) bytes, every chunk but
@@ -81,6 +91,11 @@ size_t zo_deflate_chunked(const uint8_t *in, size_t n, size_t chunk_size,
                           int level, int strategy, int mem_level,
                           uint8_t *out, size_t out_cap,
                           uint32_t *chunk_len, size_t max_chunks);
+/* the same with a window of 1 << wbits bytes (9..15): the dictionary of a chunk is the previous 1 << wbits bytes */
+size_t zo_deflate_chunked_w(const uint8_t *in, size_t n, size_t chunk_size,
+                            int level, int strategy, int mem_level, int wbits,
+                            uint8_t *out, size_t out_cap,
+                            uint32_t *chunk_len, size_t max_chunks);
 
 /* adler32.c:65, crc32.c:204 and their combine functions (adler32.c:136, crc32.c:355) */
 uint32_t zo_adler32(uint32_t adler, const uint8_t *buf, size_t len);

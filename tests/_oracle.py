@@ -44,6 +44,13 @@ def lib():
         l.zo_deflate_chunk_primed.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Trace)]
         l.zo_deflate_chunk_primed.restype = C.c_size_t
+        l.zo_deflate_chunk_ex.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(Trace),
+                                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        l.zo_deflate_chunk_ex.restype = C.c_size_t
+        l.zo_deflate_chunked_w.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_uint32), C.c_size_t]
+        l.zo_deflate_chunked_w.restype = C.c_size_t
         l.zo_trace_free.argtypes = [C.POINTER(Trace)]
         l.zo_adler32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]; l.zo_adler32.restype = C.c_uint32
         l.zo_crc32.argtypes = [C.c_uint32, C.c_char_p, C.c_size_t]; l.zo_crc32.restype = C.c_uint32
@@ -63,17 +70,26 @@ def corpus(n, kind, seed):
     return buf.raw[:n]
 
 
-def deflate_chunk(buf, dict_len, n, level=6, strategy=0, mem_level=8, final=True, want_trace=False, tune=None, prime=(0, 0)):
-    """buf = dictionary + chunk bytes.  Returns bytes, or (bytes, syms, blocks) with want_trace."""
+FLUSH_SYNC, FLUSH_FINISH, FLUSH_PARTIAL, FLUSH_BLOCK = 0, 1, 2, 3
+
+
+def deflate_chunk(buf, dict_len, n, level=6, strategy=0, mem_level=8, final=True, want_trace=False, tune=None, prime=(0, 0),
+                  wbits=15, flush=None, want_state=False):
+    """buf = dictionary + chunk bytes.  Returns bytes, or (bytes, syms, blocks) with want_trace, or
+    (bytes, pending bit count, pending bit value, data_type) with want_state.  flush (FLUSH_*) overrides final."""
     cap = n + n // 4 + 65536
     out = C.create_string_buffer(cap)
     tr = Trace()
     tv = (C.c_int * 4)(*tune) if tune else None
-    r = lib().zo_deflate_chunk_primed(bytes(buf), dict_len, n, level, strategy, mem_level, 15, int(final), tv, prime[0], prime[1],
-                                      out, cap, C.byref(tr) if want_trace else None)
+    fl = flush if flush is not None else (FLUSH_FINISH if final else FLUSH_SYNC)
+    pb, pv, dt = C.c_int(0), C.c_int(0), C.c_int(2)
+    r = lib().zo_deflate_chunk_ex(bytes(buf), dict_len, n, level, strategy, mem_level, wbits, fl, tv, prime[0], prime[1],
+                                  out, cap, C.byref(tr) if want_trace else None, C.byref(pb), C.byref(pv), C.byref(dt))
     if r == C.c_size_t(-1).value:
         raise RuntimeError("oracle deflate failed")
     data = out.raw[:r]
+    if want_state:
+        return data, pb.value, pv.value, dt.value
     if not want_trace:
         return data
     syms = [(tr.syms[i].pos, tr.syms[i].dist, tr.syms[i].lc) for i in range(tr.n_syms)]
@@ -82,13 +98,13 @@ def deflate_chunk(buf, dict_len, n, level=6, strategy=0, mem_level=8, final=True
     return data, syms, blocks
 
 
-def deflate_chunked(data, chunk_size=1 << 20, level=6, strategy=0, mem_level=8):
+def deflate_chunked(data, chunk_size=1 << 20, level=6, strategy=0, mem_level=8, wbits=15):
     n = len(data)
     cap = n + n // 4 + 65536 + (n // chunk_size + 1) * 1024
     out = C.create_string_buffer(cap)
     maxc = n // chunk_size + 2
     lens = (C.c_uint32 * maxc)()
-    r = lib().zo_deflate_chunked(bytes(data), n, chunk_size, level, strategy, mem_level, out, cap, lens, maxc)
+    r = lib().zo_deflate_chunked_w(bytes(data), n, chunk_size, level, strategy, mem_level, wbits, out, cap, lens, maxc)
     if r == C.c_size_t(-1).value:
         raise RuntimeError("oracle deflate failed")
     nch = max(1, (n + chunk_size - 1) // chunk_size)

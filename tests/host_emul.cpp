@@ -28,25 +28,26 @@ static void or_bits(std::vector<uint8_t> &out, uint64_t bit, uint64_t v, uint32_
 }
 
 /* head[]/prev[] of deflate_fast held the way the kernel holds them: 16-bit window indices */
+static int g_wbits = 15;      /* windowBits of the case at hand */
 struct HostFast {
     const uint8_t *b; const ZcParams *P;
     std::vector<uint16_t> head, prev;
     uint32_t insert(uint32_t p, uint32_t B)
     {
         uint32_t h = zc_hash3(b[p], b[p + 1], b[p + 2], P->hash_shift, P->hash_mask), e = head[h];
-        prev[(p - B) & 32767u] = (uint16_t)e; head[h] = (uint16_t)(p - B);
+        prev[(p - B) & (P->wsize - 1u)] = (uint16_t)e; head[h] = (uint16_t)(p - B);
         return e;
     }
     void slide()
     {
-        for (auto &m : head) m = m >= 32768 ? m - 32768 : 0;
-        for (auto &m : prev) m = m >= 32768 ? m - 32768 : 0;
+        for (auto &m : head) m = m >= P->wsize ? m - P->wsize : 0;
+        for (auto &m : prev) m = m >= P->wsize ? m - P->wsize : 0;
     }
     void longest(uint32_t p, uint32_t B, uint32_t cur, uint32_t look, uint32_t *mlen, uint32_t *mdist)
     {   /* lane-parallel shape of the kernel: collect the candidates, measure them all, then pick in chain order */
-        uint32_t sw = p - B, limit = sw > ZC_MAX_DIST ? sw - ZC_MAX_DIST : 0, cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
+        uint32_t sw = p - B, limit = sw > P->max_dist ? sw - P->max_dist : 0, cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
         uint32_t nice = P->nice < look ? P->nice : look, cand[32], lens[32], n = 0;
-        do { cand[n++] = cur; cur = prev[cur & 32767u]; } while (cur > limit && n < P->chain);
+        do { cand[n++] = cur; cur = prev[cur & (P->wsize - 1u)]; } while (cur > limit && n < P->chain);
         for (uint32_t k = 0; k < n; k++) { uint32_t l = 0; const uint8_t *m = b + B + cand[k], *s = b + p; while (l < cap && m[l] == s[l]) l++; lens[k] = l; }
         uint32_t best = 2, bk = 0;
         for (uint32_t k = 0; k < n; k++) { if (lens[k] > best) { best = lens[k]; bk = k; if (best >= nice) break; } }
@@ -69,6 +70,8 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
     P.lit_bufsize = 1u << (mem_level + 6);
     P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level == 0 ? ZC_PARSE_STORED : level < 4 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
     P.chunk_size = chunk_size; P.max_blocks = chunk_size / (P.lit_bufsize - 1) + 3;
+    P.wsize = 1u << g_wbits; P.max_dist = P.wsize - ZC_MIN_LOOK;
+    if (level == 0) P.max_blocks += chunk_size / P.max_dist + 4;
 
     /* k_chain: global links */
     std::vector<uint16_t> pdist(n + 4, 0);
@@ -86,7 +89,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
     uint64_t obyte = 0;
     chunk_off.clear();
     for (uint64_t c = 0; c < chunks; c++) {
-        ZcChunkGeom g = zc_geom(n, chunk_size, c, 1);
+        ZcChunkGeom g = zc_geom(n, chunk_size, c, 1, 0, P.wsize);
         uint32_t E = g.dict_len + g.len;
         HostWin win; win.b = in + g.dstart; win.n = n - g.dstart;
         const uint16_t *pdc = pdist.data() + g.dstart;
@@ -94,7 +97,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
         /* k_match */
         std::vector<uint32_t> rf(g.len + 1), rq(g.len + 1);
         if (P.parser == ZC_PARSE_SLOW)
-            for (uint32_t i = 0; i < g.len; i++) zc_match_pos(win, pd, g.dict_len + i, E, g.corner, P.nice, P.chain, &rf[i], &rq[i]);
+            for (uint32_t i = 0; i < g.len; i++) zc_match_pos(win, pd, g.dict_len + i, E, g.corner, P.nice, P.chain, &rf[i], &rq[i], P.max_dist);
         else if (P.parser == ZC_PARSE_RLE)
             for (uint32_t i = 0; i < g.len; i++) rf[i] = rq[i] = zc_rle_pos(win, g.dict_len + i, E);
         /* k_parse */
@@ -106,7 +109,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
         uint32_t nsym = 0, nb;
         if (P.parser == ZC_PARSE_FAST) {
             HostFast cx; cx.b = in + g.dstart; cx.P = &P;
-            cx.head.assign((size_t)1 << P.hash_bits, 0); cx.prev.assign(32768, 0);
+            cx.head.assign((size_t)1 << P.hash_bits, 0); cx.prev.assign(P.wsize, 0);
             nb = zc_parse_fast(g.dict_len, g.len, g.final, P, cx, symst, blkst, &nsym);
         } else
         if (P.parser == ZC_PARSE_STORED) nb = zc_parse_stored(g.dict_len, g.len, g.final, P, blkst);
@@ -171,7 +174,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
                     p_top = spos[sI] + 1;
                 }
                 B.in_start = in_start; B.in_len = in_end - in_start;
-                B.flags = ((lastb && g.final) ? ZC_BF_LAST : 0u) | (in_start >= zc_window_base(p_top, E, ZC_MIN_LOOK) ? ZC_BF_CANSTORE : 0u);
+                B.flags = ((lastb && g.final) ? ZC_BF_LAST : 0u) | (in_start >= zc_window_base(p_top, E, ZC_MIN_LOOK, P.wsize) ? ZC_BF_CANSTORE : 0u);
                 blkst(b, B); in_start = in_end;
             }
         }
@@ -265,6 +268,7 @@ int main(int argc, char **argv)
         if (kind < 5) zo_corpus_fill(in.data(), n, kind, rnd() | 1);
         else if (kind == 5) for (uint64_t i = 0; i < n; i++) in[i] = (uint8_t)('a' + rnd() % (1 + (it % 16)));
         else { uint32_t per = 1 + rnd() % 300; for (uint64_t i = 0; i < n; i++) in[i] = (uint8_t)(i < per ? rnd() : in[i - per]); for (uint64_t i = 0; i < n / 211; i++) in[rnd() % n] ^= 4; }
+        g_wbits = (rnd() % 3) ? 15 : 9 + (int)(rnd() % 6);
         int tune[4]; g_tune = NULL; g_tuned_wild = 0;
         if (g_hops == 2 && level >= 4 && rnd() % 3 == 0) {
             static const int lazies[] = {0, 1, 2, 3, 4, 5, 8, 16, 64, 258, 300}, nices[] = {3, 4, 8, 9, 32, 100, 258, 259, 1000}, chains[] = {1, 2, 3, 5, 8, 17, 40, 64, 100, 500};
@@ -279,8 +283,9 @@ int main(int argc, char **argv)
         {   /* oracle chunk loop with the same chunk size */
             size_t o = 0, offi = 0, c = 0;
             do {
-                size_t len = n - offi < cs ? n - offi : cs, dict = offi < 32768 ? offi : 32768;
-                size_t r = zo_deflate_chunk_tuned(in.data() + offi - dict, dict, len, level, strategy, mem, 15, offi + len >= n, g_tune, want.data() + o, want.size() - o, NULL);
+                const size_t wsz = (size_t)1 << g_wbits;
+                size_t len = n - offi < cs ? n - offi : cs, dict = offi < wsz ? offi : wsz;
+                size_t r = zo_deflate_chunk_tuned(in.data() + offi - dict, dict, len, level, strategy, mem, g_wbits, offi + len >= n, g_tune, want.data() + o, want.size() - o, NULL);
                 if (r == (size_t)-1) { printf("oracle failed\n"); return 1; }
                 clen[c++] = (uint32_t)r; o += r; offi += len;
             } while (offi < n);
@@ -290,7 +295,7 @@ int main(int argc, char **argv)
         if (!ok) {
             bad++;
             size_t d = 0; while (d < wl && d < got.size() && got[d] == want[d]) d++;
-            printf("MISMATCH it=%ld n=%llu cs=%u L=%d S=%d M=%d kind=%d got=%zu want=%zu first diff %zu", it, (unsigned long long)n, cs, level, strategy, mem, kind, got.size(), wl, d);
+            printf("MISMATCH it=%ld n=%llu cs=%u L=%d S=%d M=%d W=%d kind=%d got=%zu want=%zu first diff %zu", it, (unsigned long long)n, cs, level, strategy, mem, g_wbits, kind, got.size(), wl, d);
             if (g_tune) printf(" tune=%d,%d,%d,%d", g_tune[0], g_tune[1], g_tune[2], g_tune[3]);
             printf("\n");
             if (bad > 5) break;

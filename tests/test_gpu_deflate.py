@@ -255,3 +255,89 @@ def test_tuned_parameters_outside_the_tables_shape(engine, level, tune):
         dl, ln = min(start, 32768), min(chunk, len(data) - start)
         want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, level, 0, 8, c == nch - 1, tune=tune)
     assert out == want
+
+
+from test_oracle_golden import boundary_input, _ZFLUSH
+
+
+@pytest.mark.parametrize("r", GOLD["boundary"], ids=lambda r: "k%d_s%d_n%d_d%d_L%d_S%d_W%d_F%d" % (
+    r["kind"], r["seed"], r["n"], r["dict"], r["level"], r["strategy"], r["wbits"], r["flush"]))
+def test_boundary_rows_from_reference_build(engine, r):
+    """One chunk as the stream API's corner cases make it: a dictionary of any length in front (deflate.c:323-389),
+    windowBits 9..14 (deflate.c:271-291), ended by any flush value (deflate.c:923-945, trees.c:892-901), with the bits
+    the reference keeps in its bit buffer and strm->data_type (trees.c:1120-1147) — against the reference's own results."""
+    buf = boundary_input(r)
+    fl = _ZFLUSH[r["flush"]]
+    engine.window_bits(r["wbits"])
+    try:
+        if fl in (O.FLUSH_PARTIAL, O.FLUSH_BLOCK):
+            engine.tail(1 if fl == O.FLUSH_PARTIAL else 2)
+        out, _ = engine.deflate_chunks(buf[r["dict"]:], level=r["level"], strategy=r["strategy"], chunk_size=1 << 20,
+                                       finish=fl == O.FLUSH_FINISH, dictionary=buf[:r["dict"]])
+        pb, pv = engine.pending_bits()
+        dt = engine.data_type()
+    finally:
+        engine.window_bits(15)
+    assert len(out) == r["out_len"] and "%08x" % zlib.crc32(out) == r["out_crc"]
+    assert (pb, pv, dt) == (r["pend_bits"], r["pend_val"], r["data_type"])
+
+
+@pytest.mark.parametrize("wbits", [9, 10, 11, 12, 13, 14])
+def test_small_windows_over_many_chunks(engine, wbits):
+    """windowBits below 15 over several chunks (each primed with the previous 1 << wbits bytes), all parsers."""
+    engine.window_bits(wbits)
+    try:
+        for kind, n, level, strategy, mem, chunk in ((4, 300001, 6, 0, 8, 65536), (0, 200000, 1, 0, 8, 32768), (3, 150000, 9, 1, 8, 65536),
+                                                     (2, 100000, 4, 3, 3, 32768), (4, 250000, 3, 0, 9, 131072), (1, 140000, 0, 0, 8, 65536),
+                                                     (0, 65536 + 65274 - (1 << wbits), 6, 0, 8, 65536), (4, 90000, 6, 2, 8, 32768)):
+            data = O.corpus(n, kind, 200 + wbits)
+            out, lens = _gpu(engine, data, level=level, strategy=strategy, mem_level=mem, chunk_size=chunk)
+            want, wlens = O.deflate_chunked(data, chunk, level, strategy, mem, wbits=wbits)
+            assert lens == wlens and out == want, (kind, n, level, strategy, mem, chunk)
+            assert zlib.decompress(out, -15) == data
+    finally:
+        engine.window_bits(15)
+
+
+@pytest.mark.parametrize("dlen", [1, 2, 3, 15, 17, 1001, 12345, 32767, 32768])
+def test_dictionary_of_any_length_then_several_chunks(engine, dlen):
+    """A preset dictionary of any length primes the first chunk; the later chunks see (dictionary ++ data) as history."""
+    d = O.corpus(dlen, 0, 300)
+    data = O.corpus(3 * 65536 + 99, 0, 301)
+    for level in (1, 6):
+        out, lens = _gpu(engine, data, level=level, chunk_size=65536, dictionary=d)
+        hist = d + data
+        want = b""
+        for c in range(4):
+            start = dlen + c * 65536
+            ln = min(65536, len(hist) - start)
+            dl = min(start, 32768)
+            want += O.deflate_chunk(hist[start - dl:start + ln], dl, ln, level, 0, 8, final=(c == 3))
+        assert out == want, (dlen, level)
+
+
+@pytest.mark.parametrize("flush", [O.FLUSH_PARTIAL, O.FLUSH_BLOCK])
+def test_partial_flush_and_block_in_the_middle_of_a_stream(engine, flush):
+    """A call of several chunks ended by Z_PARTIAL_FLUSH / Z_BLOCK: the chunks inside still end on sync markers, the last
+    one as the flush value says; the bits left over lead the next call (zamd_engine_prime), and the whole is one stream."""
+    data = O.corpus(2 * 65536 + 5000, 0, 310) + O.corpus(70000, 4, 311)
+    cut = 2 * 65536 + 5000
+    engine.tail(1 if flush == O.FLUSH_PARTIAL else 2)
+    a, _ = engine.deflate_chunks(data[:cut], level=6, chunk_size=65536, finish=False)
+    pb, pv = engine.pending_bits()
+    want = b""
+    for c in range(3):
+        s0 = c * 65536
+        ln = min(65536, cut - s0)
+        dl = min(s0, 32768)
+        if c < 2:
+            want += O.deflate_chunk(data[s0 - dl:s0 + ln], dl, ln, 6, 0, 8, final=False)
+        else:
+            w, wpb, wpv, _ = O.deflate_chunk(data[s0 - dl:s0 + ln], dl, ln, 6, 0, 8, flush=flush, want_state=True)
+            want += w
+    assert a == want and (pb, pv) == (wpb, wpv)
+    if pb:
+        engine.prime(pb, pv)
+    b, _ = engine.deflate_chunks(data[cut:], level=6, chunk_size=65536, finish=True, dictionary=data[cut - 32768:cut])
+    # the second call's first byte holds the leftover bits in its low end: it replaces nothing of the first call
+    assert zlib.decompress(a + b, -15) == data

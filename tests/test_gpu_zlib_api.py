@@ -257,24 +257,90 @@ def _deflate_with_dict(data, d, level=6, wbits=15):
 
 def test_preset_dictionary_on_deflate():
     data = O.corpus(200000, 0, 31)
-    # a dictionary the engine can take whole (multiple of 16 bytes): the reference's bytes exactly
-    d = O.corpus(16000, 0, 31)
-    out, adler = _deflate_with_dict(data, d)
-    want = bytes([0x78, 0xbb]) + zlib.adler32(d).to_bytes(4, "big") + O.deflate_chunk(d + data, len(d), len(data), 6, 0, 8, True) \
-        + zlib.adler32(data).to_bytes(4, "big")
-    assert out == want
-    assert adler == zlib.adler32(data)
-    assert zlib.decompressobj(15, d).decompress(out) == data
-    # any other length, and more than a window: valid streams for the same dictionary
-    for dl in (1, 15, 1001, 32768, 50000):
+    # dictionaries of any length, also longer than the window (the last 32 KiB count, the id covers all of it,
+    # deflate.c:323-389): the reference's bytes exactly
+    for dl in (1, 15, 1001, 16000, 32768, 50000):
         d = O.corpus(dl, 0, 32)
-        out, _ = _deflate_with_dict(data, d)
+        out, adler = _deflate_with_dict(data, d)
+        k = d[-32768:]
+        want = bytes([0x78, 0xbb]) + zlib.adler32(d).to_bytes(4, "big") + O.deflate_chunk(k + data, len(k), len(data), 6, 0, 8, True) \
+            + zlib.adler32(data).to_bytes(4, "big")
+        assert out == want, dl
+        assert adler == zlib.adler32(data)
         assert zlib.decompressobj(15, d).decompress(out) == data
         raw, _ = _deflate_with_dict(data, d, wbits=-15)
-        assert zlib.decompressobj(-15, d).decompress(raw) == data
+        assert raw == O.deflate_chunk(k + data, len(k), len(data), 6, 0, 8, True), dl
     # our own inflate takes it back through Z_NEED_DICT
     rc, back, msg, unused, _ = Z.inflate_stream(out, 15, dictionary=d)
     assert rc == Z.Z_STREAM_END and back == data
+
+
+@pytest.mark.parametrize("wbits", [8, 9, 10, 11, 12, 13, 14])
+def test_deflate_with_a_small_window(wbits):
+    """windowBits 8..14 (deflate.c:271-291; 8 becomes 9, :276): header, body and trailer as the reference writes them."""
+    data = O.corpus(150000, 4, 40 + wbits)
+    w = max(wbits, 9)
+    out, totals = Z.deflate_stream(data, 6, wbits)
+    hdr = (8 + ((w - 8) << 4)) << 8 | (2 << 6)
+    hdr += 31 - hdr % 31
+    want = hdr.to_bytes(2, "big") + O.deflate_chunk(data, 0, len(data), 6, 0, 8, True, wbits=w) + zlib.adler32(data).to_bytes(4, "big")
+    assert out == want
+    assert zlib.decompress(out) == data
+    raw, _ = Z.deflate_stream(data, 9, -wbits)
+    assert raw == O.deflate_chunk(data, 0, len(data), 9, 0, 8, True, wbits=w)
+    gz, _ = Z.deflate_stream(data, 1, 16 + wbits)
+    assert gz[10:-8] == O.deflate_chunk(data, 0, len(data), 1, 0, 8, True, wbits=w)
+    # several chunks and a dictionary with the same window
+    big = O.corpus(3 * (1 << 20) // 8, 0, 41)
+    comp, _ = Z.deflate_stream(big, 6, -wbits, in_step=100000)
+    assert zlib.decompressobj(-15).decompress(comp) == big
+
+
+@pytest.mark.parametrize("flush", [Z.Z_PARTIAL_FLUSH, Z.Z_BLOCK])
+def test_partial_flush_and_block_are_the_references_bits(flush):
+    """Z_PARTIAL_FLUSH ends the data with _tr_align's 10 bits (trees.c:892-901), Z_BLOCK with nothing (deflate.c:923-925);
+    both leave up to seven bits in the bit buffer (deflatePending), which lead the next block."""
+    data = O.corpus(120000, 0, 50)
+    l = Z.lib()
+    s = Z.ZStream()
+    assert l.deflateInit2_(C.byref(s), 6, 8, -15, 8, 0, Z.VERSION, Z.SZ) == 0
+    src = C.create_string_buffer(data, len(data))
+    obuf = C.create_string_buffer(1 << 20)
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), 70000, C.addressof(obuf), 1 << 20
+    assert l.deflate(C.byref(s), flush) == Z.Z_OK
+    first = obuf.raw[:s.total_out]
+    want, pb, pv, dt = O.deflate_chunk(data[:70000], 0, 70000, 6, 0, 8, flush=O.FLUSH_PARTIAL if flush == Z.Z_PARTIAL_FLUSH else O.FLUSH_BLOCK,
+                                       want_state=True)
+    assert first == want
+    pend, bits = C.c_uint(99), C.c_int(99)
+    assert l.deflatePending(C.byref(s), C.byref(pend), C.byref(bits)) == Z.Z_OK
+    assert (pend.value, bits.value) == (0, pb)
+    assert s.data_type == dt == 1
+    # the rest of the input: a chunk of its own, primed with the history and led by the bits left over
+    s.avail_in = 50000
+    assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+    whole = obuf.raw[:s.total_out]
+    rest = O.deflate_chunk(data[70000 - 32768:], 32768, 50000, 6, 0, 8, True, prime=(pb, pv))
+    assert whole == first + rest
+    assert zlib.decompressobj(-15).decompress(whole) == data
+    assert l.deflateEnd(C.byref(s)) == Z.Z_OK
+
+
+def test_data_type_is_set_from_the_first_block():
+    """strm->data_type after deflate (trees.c:920-921, 1120-1147): Z_TEXT / Z_BINARY from the first block's literals at
+    level > 0, untouched (Z_UNKNOWN) at level 0."""
+    l = Z.lib()
+    for kind, level, want in ((0, 6, 1), (1, 6, 0), (4, 1, O.deflate_chunk(O.corpus(90000, 4, 60), 0, 90000, 1, want_state=True)[3]), (0, 0, 2), (3, 9, 0)):
+        data = O.corpus(90000, kind, 60)
+        s = Z.ZStream()
+        assert l.deflateInit2_(C.byref(s), level, 8, 15, 8, 0, Z.VERSION, Z.SZ) == 0
+        assert s.data_type == 2
+        src = C.create_string_buffer(data, len(data))
+        obuf = C.create_string_buffer(1 << 20)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(data), C.addressof(obuf), 1 << 20
+        assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+        assert s.data_type == want, (kind, level)
+        assert l.deflateEnd(C.byref(s)) == Z.Z_OK
 
 
 def test_preloaded_under_a_program_linked_against_libz():

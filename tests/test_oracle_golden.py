@@ -180,3 +180,22 @@ def test_inflate_oracle_on_reference_raw_vectors():
         rc, out, used, msg = O.inflate_raw(comp, b"", 1 << 20)
         assert msg == v["msg"], v
         assert (rc == 0) == (v["msg"] is None)
+
+
+_ZFLUSH = {2: O.FLUSH_SYNC, 3: O.FLUSH_SYNC, 4: O.FLUSH_FINISH, 1: O.FLUSH_PARTIAL, 5: O.FLUSH_BLOCK}   # zlib.h:162-167 -> oracle
+
+
+def boundary_input(r):
+    """dictionary ++ chunk of a "boundary" row of the golden file (oracle/gen_golden.c: boundary_row)."""
+    return O.corpus(r["dict"], r["kind"], r["seed"] + 1000) + O.corpus(r["n"], r["kind"], r["seed"])
+
+
+@pytest.mark.parametrize("r", GOLD["boundary"], ids=lambda r: "k%d_s%d_n%d_d%d_L%d_S%d_W%d_F%d" % (
+    r["kind"], r["seed"], r["n"], r["dict"], r["level"], r["strategy"], r["wbits"], r["flush"]))
+def test_boundary_rows(r):
+    """Dictionaries of any length, windowBits 9..14, every flush value: bytes, the bits left in the bit buffer and
+    strm->data_type as the reference build produced them."""
+    out, pb, pv, dt = O.deflate_chunk(boundary_input(r), r["dict"], r["n"], r["level"], r["strategy"], 8, wbits=r["wbits"],
+                                      flush=_ZFLUSH[r["flush"]], want_state=True)
+    assert len(out) == r["out_len"] and "%08x" % zlib.crc32(out) == r["out_crc"]
+    assert (pb, pv, dt) == (r["pend_bits"], r["pend_val"], r["data_type"])

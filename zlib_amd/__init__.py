@@ -63,6 +63,14 @@ def load_library() -> C.CDLL:
     lib.zamd_find_sync_dev.restype = i32
     lib.zamd_find_blocks_dev.argtypes = [vp, vp, u64, C.POINTER(u64), C.c_uint32, u64, C.POINTER(u64)]
     lib.zamd_find_blocks_dev.restype = i32
+    lib.zamd_engine_window_bits.argtypes = [vp, i32]
+    lib.zamd_engine_window_bits.restype = i32
+    lib.zamd_engine_tail.argtypes = [vp, i32]
+    lib.zamd_engine_tail.restype = i32
+    lib.zamd_engine_pending_bits.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.zamd_engine_pending_bits.restype = i32
+    lib.zamd_engine_data_type.argtypes = [vp]
+    lib.zamd_engine_data_type.restype = i32
     lib.zamd_engine_prime.argtypes = [vp, i32, i32]
     lib.zamd_engine_prime.restype = i32
     lib.zamd_checksums_dev.argtypes = [vp, vp, u64, u32, vp, vp]
@@ -208,6 +216,24 @@ class Engine:
         """deflatePrime for the next deflate call: `bits` (0..7) bits of `value` in front of its first block."""
         _chk(self.lib.zamd_engine_prime(self.handle, bits, value), "zamd_engine_prime")
 
+    def window_bits(self, bits: int = 15) -> None:
+        """windowBits (9..15) of the following deflate calls."""
+        _chk(self.lib.zamd_engine_window_bits(self.handle, bits), "zamd_engine_window_bits")
+
+    def tail(self, mode: int) -> None:
+        """How the next deflate call ends when finish is false: 0 sync marker, 1 _tr_align (Z_PARTIAL_FLUSH), 2 nothing (Z_BLOCK)."""
+        _chk(self.lib.zamd_engine_tail(self.handle, mode), "zamd_engine_tail")
+
+    def pending_bits(self) -> Tuple[int, int]:
+        """(count, value) of the bits the last deflate call left behind its last whole byte."""
+        b, v = C.c_int(0), C.c_int(0)
+        _chk(self.lib.zamd_engine_pending_bits(self.handle, C.byref(b), C.byref(v)), "zamd_engine_pending_bits")
+        return b.value, v.value
+
+    def data_type(self) -> int:
+        """strm->data_type after the last deflate call: 0 Z_BINARY, 1 Z_TEXT, 2 Z_UNKNOWN."""
+        return self.lib.zamd_engine_data_type(self.handle)
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
@@ -246,18 +272,27 @@ class Engine:
 
     # -- host convenience (upload, run on the GPU, download) ---------------------------
     def deflate_chunks(self, data, *, level: int = 6, strategy: int = 0, mem_level: int = 8,
-                       chunk_size: int = 1 << 20, finish: bool = True) -> Tuple[bytes, List[int]]:
-        """Chunked raw deflate of host bytes; returns (stream, chunk offsets + total)."""
+                       chunk_size: int = 1 << 20, finish: bool = True, dictionary: bytes = b"") -> Tuple[bytes, List[int]]:
+        """Chunked raw deflate of host bytes; returns (stream, chunk offsets + total).  `dictionary` (at most the
+        window size) primes the first chunk as deflateSetDictionary does."""
         n = len(data)
         nchunks = max(1, (n + chunk_size - 1) // chunk_size)
         cap = self.lib.zamd_deflate_bound(n, chunk_size, mem_level)
-        d_in = self.alloc(max(n, 16))
+        d_stage = self.alloc(32768 + max(n, 16))
+        d_in = DeviceBuffer.__new__(DeviceBuffer)
+        d_in.engine, d_in.nbytes, d_in.ptr = self, max(n, 16), d_stage.ptr + 32768
+        d_in.free = lambda: d_stage.free()
         d_out = self.alloc(cap)
         d_off = self.alloc(8 * (nchunks + 1))
         try:
             d_in.upload(data)
-            total = self.deflate_dev(d_in.ptr, n, d_out.ptr, cap, level=level, strategy=strategy, mem_level=mem_level,
-                                     chunk_size=chunk_size, finish=finish, d_chunk_off=d_off.ptr)
+            if dictionary:
+                d_stage.upload(dictionary, 32768 - len(dictionary))
+                total = self.deflate_shard_dev(d_in.ptr, n, len(dictionary), d_out.ptr, cap, level=level, strategy=strategy,
+                                               mem_level=mem_level, chunk_size=chunk_size, finish=finish, d_chunk_off=d_off.ptr)
+            else:
+                total = self.deflate_dev(d_in.ptr, n, d_out.ptr, cap, level=level, strategy=strategy, mem_level=mem_level,
+                                         chunk_size=chunk_size, finish=finish, d_chunk_off=d_off.ptr)
             out = bytes(d_out.download(total))
             offs = list(memoryview(d_off.download(8 * (nchunks + 1))).cast("Q"))
         finally:

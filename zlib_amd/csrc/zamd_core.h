@@ -26,7 +26,7 @@
 #define ZC_HD inline
 #endif
 
-#define ZC_WSIZE     32768u                 /* windowBits 15 */
+#define ZC_WSIZE     32768u                 /* windowBits 15: the largest window; smaller ones (deflate.c:284) come in ZcParams */
 #define ZC_MIN_MATCH 3u                     /* zutil.h:75 */
 #define ZC_MAX_MATCH 258u                   /* zutil.h:76 */
 #define ZC_MIN_LOOK  262u                   /* deflate.h:281 */
@@ -55,7 +55,12 @@ struct ZcParams {
     uint32_t parser;                           /* ZC_PARSE_* */
     uint32_t chunk_size;
     uint32_t max_blocks;                       /* per-chunk capacity of the block table */
+    uint32_t wsize, max_dist;                  /* 1 << windowBits, wsize - MIN_LOOKAHEAD (deflate.c:284, deflate.h:286) */
+    uint32_t tail;                             /* how the call's last chunk ends when it is not final: ZC_TAIL_* */
 };
+enum { ZC_TAIL_SYNC = 0,    /* Z_SYNC_FLUSH / Z_FULL_FLUSH: empty stored block, byte aligned (deflate.c:926-927) */
+       ZC_TAIL_ALIGN = 1,   /* Z_PARTIAL_FLUSH: _tr_align, an empty static block of 10 bits (trees.c:892-901) */
+       ZC_TAIL_NONE = 2 };  /* Z_BLOCK: the last block is complete, nothing follows it (deflate.c:923-925) */
 
 struct ZcBlock {                 /* one _tr_flush_block() call */
     uint32_t sym_start, sym_count;
@@ -76,21 +81,22 @@ struct ZcChunkGeom {
  * position whose head candidate at distance exactly MAX_DIST is lost to a
  * window slide in tail mode (fill_window called with no input left,
  * deflate.c:1419-1451), or ZC_NO_CORNER. */
-ZC_HD ZcChunkGeom zc_geom(uint64_t n, uint32_t chunk_size, uint64_t c, int finish, uint32_t head = 0)
+ZC_HD ZcChunkGeom zc_geom(uint64_t n, uint32_t chunk_size, uint64_t c, int finish, uint32_t head = 0, uint32_t wsize = ZC_WSIZE)
 {
-    /* `head` bytes (0 or 32768) in front of chunk 0 belong to the buffer and are
-     * chunk 0's dictionary: a shard that continues somebody else's stream */
+    /* `head` bytes (at most wsize) in front of chunk 0 belong to the buffer and are
+     * chunk 0's dictionary: a shard that continues somebody else's stream, or a preset dictionary */
+    const uint32_t maxd = wsize - ZC_MIN_LOOK;
     ZcChunkGeom g;
     uint64_t start = head + c * (uint64_t)chunk_size;
     uint64_t rem = n - start;
     g.len = (uint32_t)(rem < chunk_size ? rem : chunk_size);
-    g.dict_len = (uint32_t)(start < ZC_WSIZE ? start : ZC_WSIZE);
+    g.dict_len = (uint32_t)(start < wsize ? start : wsize);
     g.dstart = start - g.dict_len;
     g.final = (finish && start + g.len >= n) ? 1u : 0u;
     uint32_t E = g.dict_len + g.len;
-    uint32_t bt = E <= 2 * ZC_WSIZE ? 0u : ((E - 2 * ZC_WSIZE + ZC_WSIZE - 1) / ZC_WSIZE) * ZC_WSIZE;
+    uint32_t bt = E <= 2 * wsize ? 0u : ((E - 2 * wsize + wsize - 1) / wsize) * wsize;
     uint32_t tail = E - bt;       /* data end as a window index in the last window */
-    g.corner = (tail >= ZC_WSIZE + ZC_MAX_DIST + 3 && tail <= 2 * ZC_WSIZE - 1) ? bt + ZC_WSIZE + ZC_MAX_DIST : ZC_NO_CORNER;
+    g.corner = (tail >= wsize + maxd + 3 && tail <= 2 * wsize - 1) ? bt + wsize + maxd : ZC_NO_CORNER;
     return g;
 }
 
@@ -210,21 +216,22 @@ ZC_HD uint32_t zc_sym_bits(uint32_t sym, uint32_t lit_byte, const LTab &ltab, co
  * none within 32767).  Result words: len | dist << 16, len = 0 for "no match".
  */
 struct ZcMatchState {
-    uint32_t p, cur, k, best, bdist, qrec, cap, nice, scan3, qset;
+    uint32_t p, cur, k, best, bdist, qrec, cap, nice, scan3, qset, maxd;
 };
 
 /* Sets up the walk for position p.  Returns false when p has no usable head
  * candidate (its record is then 0, 0). */
 template <class Win, class Pd>
 ZC_HD bool zc_match_init(const Win &win, const Pd &pd, uint32_t p, uint32_t E, uint32_t corner,
-                         uint32_t nice_match, ZcMatchState &s)
+                         uint32_t nice_match, ZcMatchState &s, uint32_t max_dist = ZC_MAX_DIST)
 {
+    s.maxd = max_dist;
     uint32_t look = E - p;
     if (look < ZC_MIN_MATCH) return false;                 /* no INSERT_STRING, deflate.c:1756 */
     uint32_t d0 = pd(p);
-    if (d0 == 0 || d0 > ZC_MAX_DIST) return false;         /* hash_head == NIL or too far, :1765-1766 */
+    if (d0 == 0 || d0 > max_dist) return false;            /* hash_head == NIL or too far, :1765-1766 */
     if (d0 >= p) return false;                             /* window index 0 is NIL */
-    if (p == corner && d0 == ZC_MAX_DIST) return false;    /* slid onto index 0 in tail mode */
+    if (p == corner && d0 == max_dist) return false;       /* slid onto index 0 in tail mode */
     s.p = p; s.cur = p - d0; s.k = 0; s.best = ZC_MIN_MATCH - 1; s.bdist = 0; s.qrec = 0; s.qset = 0;
     s.cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
     s.nice = nice_match < look ? nice_match : look;        /* :1191 */
@@ -272,7 +279,7 @@ ZC_HD bool zc_match_advance(ZcMatchState &s, uint32_t d, uint32_t max_chain)
     if (s.k >= max_chain) return true;
     if (d == 0 || d >= s.cur) return true;                 /* end of chain, or window index <= 0 */
     s.cur -= d;
-    return s.p - s.cur >= ZC_MAX_DIST;                     /* cur <= limit, :1158, 1284 */
+    return s.p - s.cur >= s.maxd;                          /* cur <= limit, :1158, 1284 */
 }
 
 /* Examines the candidate s.cur and moves to the next chain member.  Returns
@@ -296,11 +303,12 @@ ZC_HD void zc_match_result(const ZcMatchState &s, uint32_t max_chain, uint32_t *
 
 template <class Win, class Pd>
 ZC_HD void zc_match_pos(const Win &win, const Pd &pd, uint32_t p, uint32_t E, uint32_t corner,
-                        uint32_t nice_match, uint32_t max_chain, uint32_t *rec_full, uint32_t *rec_quarter)
+                        uint32_t nice_match, uint32_t max_chain, uint32_t *rec_full, uint32_t *rec_quarter,
+                        uint32_t max_dist = ZC_MAX_DIST)
 {
     ZcMatchState s;
     *rec_full = 0; *rec_quarter = 0;
-    if (!zc_match_init(win, pd, p, E, corner, nice_match, s)) return;
+    if (!zc_match_init(win, pd, p, E, corner, nice_match, s, max_dist)) return;
     while (!zc_match_step(win, pd, max_chain, s)) {}
     zc_match_result(s, max_chain, rec_full, rec_quarter);
 }
@@ -327,11 +335,11 @@ ZC_HD uint32_t zc_rle_pos(const Win &win, uint32_t p, uint32_t E)
  * over the whole chunk (deflate.c:1390-1494).  B = a-coordinate of window index
  * 0, wend = end of the data currently in the window. */
 struct ZcWindow {
-    uint32_t B, wend, E;
+    uint32_t B, wend, E, W;       /* W = window size */
     ZC_HD void refill(uint32_t p)
     {
-        if (p - B >= ZC_WSIZE + ZC_MAX_DIST) B += ZC_WSIZE;
-        uint64_t cap = (uint64_t)B + 2u * ZC_WSIZE;
+        if (p - B >= W + (W - ZC_MIN_LOOK)) B += W;
+        uint64_t cap = (uint64_t)B + 2u * W;
         wend = E < cap ? E : (uint32_t)cap;
     }
 };
@@ -367,7 +375,7 @@ template <class Rec, class Sym, class Blk>
 ZC_HD uint32_t zc_parse_slow(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P,
                              Rec rec, Sym sym, Blk blk, uint32_t *nsym_out)
 {
-    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len; w.W = P.wsize;
     ZcSink<Sym, Blk> out(sym, blk, dict_len, P.lit_bufsize);
     uint32_t p = dict_len, mlen = ZC_MIN_MATCH - 1, mdist = 0, avail = 0;
     for (;;) {
@@ -458,7 +466,7 @@ ZC_HD bool zc_walk_direct(const Win &win, const Pd &pd, uint32_t q, uint32_t E, 
                           uint32_t plen, uint32_t *len, uint32_t *dist)
 {
     ZcMatchState s;
-    if (!zc_match_init(win, pd, q, E, corner, P.nice, s)) return false;
+    if (!zc_match_init(win, pd, q, E, corner, P.nice, s, P.max_dist)) return false;
     if (plen >= s.cap) return false;                       /* nothing can be longer than prev_length */
     if (plen > ZC_MIN_MATCH - 1) { s.best = plen; s.scan3 = win.load4(q + plen - 2u) & 0x00ffffffu; }
     uint32_t budget = plen >= P.good ? P.chain >> 2 : P.chain;
@@ -491,16 +499,19 @@ ZC_HD uint32_t zc_hop_direct(const Win &win, const Pd &pd, uint32_t p, uint32_t 
  * starts at p_top, for a chunk that ends at E: fill_window slides by 32 KiB at
  * the first iteration top that is both short of lookahead (< look_thr bytes
  * left in the window) and at window index >= 65274 (deflate.c:1419, 1744). */
-ZC_HD uint32_t zc_window_base(uint32_t p_top, uint32_t E, uint32_t look_thr)
+ZC_HD uint32_t zc_window_base(uint32_t p_top, uint32_t E, uint32_t look_thr, uint32_t wsize = ZC_WSIZE)
 {
-    uint32_t B = 0;
+    /* the base in force at p_top is the smallest multiple B of wsize with p_top < thr(B), and thr(B) <= B + 2 wsize - 261:
+     * every B below (p_top / wsize - 2) * wsize fails, so the search may start there (a small window slides thousands
+     * of times in a chunk) */
+    uint32_t B = p_top >= 3u * wsize ? (p_top / wsize - 3u) * wsize : 0u;
     for (;;) {
-        uint64_t cap = (uint64_t)B + 2u * ZC_WSIZE;
+        uint64_t cap = (uint64_t)B + 2u * wsize;
         uint32_t wend = E < cap ? E : (uint32_t)cap;
-        uint32_t t1 = wend >= look_thr - 1 ? wend - (look_thr - 1) : 0, t2 = B + ZC_WSIZE + ZC_MAX_DIST;
+        uint32_t t1 = wend >= look_thr - 1 ? wend - (look_thr - 1) : 0, t2 = B + wsize + (wsize - ZC_MIN_LOOK);
         uint32_t thr = t1 > t2 ? t1 : t2;
         if (p_top < thr) return B;
-        B += ZC_WSIZE;
+        B += wsize;
     }
 }
 
@@ -520,7 +531,7 @@ template <class Rec, class Sym, class Blk>
 ZC_HD uint32_t zc_parse_rle(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P,
                             Rec rec, Sym sym, Blk blk, uint32_t *nsym_out)
 {
-    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len; w.W = P.wsize;
     ZcSink<Sym, Blk> out(sym, blk, dict_len, P.lit_bufsize);
     uint32_t p = dict_len;
     for (;;) {
@@ -553,7 +564,7 @@ template <class Ctx, class Sym, class Blk>
 ZC_HD uint32_t zc_parse_fast(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P,
                              Ctx &cx, Sym sym, Blk blk, uint32_t *nsym_out)
 {
-    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len; w.W = P.wsize;
     ZcSink<Sym, Blk> out(sym, blk, dict_len, P.lit_bufsize);
     /* deflateSetDictionary inserts every dictionary string; the last two wait for
      * the first input bytes (deflate.c:364-381, 1471-1489) */
@@ -568,7 +579,7 @@ ZC_HD uint32_t zc_parse_fast(uint32_t dict_len, uint32_t len, uint32_t final_, c
         }
         uint32_t look = w.wend - p, hh = 0, mlen = 0, mdist = 0;
         if (look >= ZC_MIN_MATCH) hh = cx.insert(p, w.B);
-        if (hh != 0 && (p - w.B) - hh <= ZC_MAX_DIST) cx.longest(p, w.B, hh, look, &mlen, &mdist);
+        if (hh != 0 && (p - w.B) - hh <= P.max_dist) cx.longest(p, w.B, hh, look, &mlen, &mdist);
         bool f;
         if (mlen >= ZC_MIN_MATCH) {
             f = out.emit(zc_sym_match(mlen, mdist));
@@ -592,7 +603,7 @@ ZC_HD uint32_t zc_parse_fast(uint32_t dict_len, uint32_t len, uint32_t final_, c
 template <class Blk>
 ZC_HD uint32_t zc_parse_stored(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P, Blk blk)
 {
-    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len;
+    ZcWindow w; w.B = 0; w.E = dict_len + len; w.wend = dict_len; w.W = P.wsize;
     uint32_t max_block = P.lit_bufsize * 4u - 5u;
     if (max_block > 0xffffu) max_block = 0xffffu;
     uint32_t p = dict_len, look = 0, bstart = dict_len, nblk = 0;
@@ -606,7 +617,7 @@ ZC_HD uint32_t zc_parse_stored(uint32_t dict_len, uint32_t len, uint32_t final_,
         p += look; look = 0;
         const uint32_t max_start = bstart + max_block;
         if (p >= max_start) { look = p - max_start; p = max_start; flush(0); }
-        if (p - bstart >= ZC_MAX_DIST) flush(0);
+        if (p - bstart >= P.max_dist) flush(0);
     }
     if (final_) flush(1);
     else if (p > bstart) flush(0);
@@ -618,15 +629,21 @@ ZC_HD uint32_t zc_parse_stored(uint32_t dict_len, uint32_t len, uint32_t final_,
 template <class Blk>
 ZC_HD uint32_t zc_parse_huff(uint32_t dict_len, uint32_t len, uint32_t final_, const ZcParams &P, Blk blk)
 {
-    uint32_t lim = P.lit_bufsize - 1, nblk = 0, done = 0;
+    /* A block can be stored only while its start is still inside the window (deflate.c:1539-1541).  fill_window runs
+     * when the lookahead is used up (:1942), so the base in force is that of the iteration in which the flush happens:
+     * the one of the block's last byte, or, for the block flushed after the loop, the one that found no more input. */
+    const uint32_t lim = P.lit_bufsize - 1, E = dict_len + len;
+    uint32_t nblk = 0, done = 0;
     while (len - done >= lim) {
         ZcBlock b; b.sym_start = done; b.sym_count = lim; b.in_start = dict_len + done; b.in_len = lim;
-        b.flags = ZC_BF_CANSTORE | ZC_BF_IMPLICIT; b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
+        b.flags = ZC_BF_IMPLICIT | (b.in_start >= zc_window_base(b.in_start + lim - 1u, E, 1u, P.wsize) ? ZC_BF_CANSTORE : 0u);
+        b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
         blk(nblk++, b); done += lim;
     }
     if (final_ || len != done) {
         ZcBlock b; b.sym_start = done; b.sym_count = len - done; b.in_start = dict_len + done; b.in_len = len - done;
-        b.flags = ZC_BF_CANSTORE | ZC_BF_IMPLICIT | (final_ ? ZC_BF_LAST : 0u); b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
+        b.flags = ZC_BF_IMPLICIT | (final_ ? ZC_BF_LAST : 0u) | (b.in_start >= zc_window_base(E, E, 1u, P.wsize) ? ZC_BF_CANSTORE : 0u);
+        b.type = 0; b.bits = 0; b.hdr_bits = 0; b.bit_off = 0;
         blk(nblk++, b);
     }
     return nblk;
@@ -859,8 +876,11 @@ ZC_HD void zc_plan_block(ZcTree<ZC_L_CODES> &lt, ZcTree<ZC_D_CODES> &dt, ZcTree<
  * a non-final chunk ends with the empty stored block of Z_SYNC_FLUSH
  * (deflate.c:926-927), a final one is padded by bi_windup (trees.c:996-1001). */
 template <class BlkAt>
-ZC_HD uint64_t zc_layout_chunk(BlkAt blk_at, uint32_t nblk, uint32_t final_, uint64_t *sync_bit_off, uint32_t start_bit = 0)
+ZC_HD uint64_t zc_layout_chunk(BlkAt blk_at, uint32_t nblk, uint32_t final_, uint64_t *sync_bit_off, uint32_t start_bit = 0,
+                               uint32_t tail = ZC_TAIL_SYNC, uint32_t *left_bits = nullptr)
 {
+    /* tail != ZC_TAIL_SYNC: the chunk ends inside a byte; the return value counts its complete bytes and *left_bits
+     * the bits of the next one (bi_flush keeps them in the bit buffer, trees.c:1169-1181) */
     uint64_t bit = start_bit;      /* bits deflatePrime left in the bit buffer (deflate.c:464-487) */
     for (uint32_t i = 0; i < nblk; i++) {
         ZcBlock *b = blk_at(i);
@@ -868,8 +888,14 @@ ZC_HD uint64_t zc_layout_chunk(BlkAt blk_at, uint32_t nblk, uint32_t final_, uin
         if (b->type == 0) { bit += 3; bit = (bit + 7) & ~7ull; bit += 32 + 8ull * b->in_len; }
         else bit += b->bits;
     }
+    if (left_bits) *left_bits = 0;
     if (final_) bit = (bit + 7) & ~7ull;
-    else { *sync_bit_off = bit; bit += 3; bit = (bit + 7) & ~7ull; bit += 32; }
+    else if (tail == ZC_TAIL_SYNC) { *sync_bit_off = bit; bit += 3; bit = (bit + 7) & ~7ull; bit += 32; }
+    else {
+        *sync_bit_off = bit;
+        if (tail == ZC_TAIL_ALIGN) bit += 10;      /* 3 header bits of a static block + the 7-bit end-of-block code */
+        if (left_bits) *left_bits = (uint32_t)(bit & 7u);
+    }
     return bit >> 3;
 }
 

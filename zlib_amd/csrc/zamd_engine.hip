@@ -49,6 +49,7 @@ enum { ZE_CHAIN_ORDER = 1, ZE_BLOCK_OVERFLOW = 2, ZE_OUT_OVERFLOW = 4, ZE_INFLAT
 struct ZkJob {
     const uint8_t *in; uint64_t n;
     uint64_t chunk0; uint32_t nchunks; int finish; uint32_t head;
+    uint64_t last_chunk;          /* absolute number of the call's last chunk: the one P.tail applies to */
     uint32_t prime_bits, prime_val;  /* deflatePrime bits in front of the call's first chunk */
     ZcParams P;
     uint16_t *pdist; uint64_t pdist_base, pdist_len;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     __shared__ uint16_t s_link[2][ZK_CHAIN_ROUND];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t c = J.chunk0 + blockIdx.x;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head, J.P.wsize);
     const uint32_t E = g.dict_len + g.len;
     /* positions with three bytes available in the whole input */
     uint64_t avail = J.n - g.dstart;
@@ -94,15 +95,17 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     const uint8_t *src = J.in + g.dstart;
     uint16_t *pd = J.pdist + (g.dstart - J.pdist_base);
     const uint32_t passes = J.P.hash_bits > 15 ? (1u << (J.P.hash_bits - 15)) : 1u;
-    /* the two aligned words that hold bytes a..a+2, fetched one round ahead */
+    /* the two aligned words that hold bytes a..a+2, fetched one round ahead.  A dictionary of any length in front
+     * of the first chunk leaves a-coordinate 0 at any address: `mis` is its offset from a dword boundary. */
+    const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
     auto fetch = [&](uint32_t a, uint32_t &w0, uint32_t &w1) {
         w0 = 0; w1 = 0;
         if (a < Ex) {
-            uint32_t al = a & ~3u;
-            if (g.dstart + al + 8 <= J.n) { w0 = *(const uint32_t *)(src + al); w1 = *(const uint32_t *)(src + al + 4); }
+            const uint32_t al = (a + mis) & ~3u;          /* offset of the aligned word from src - mis */
+            if (al >= mis && g.dstart + (al - mis) + 8 <= J.n) { w0 = *(const uint32_t *)(src - mis + al); w1 = *(const uint32_t *)(src - mis + al + 4); }
             else {
                 uint32_t b3 = (uint32_t)src[a] | ((uint32_t)src[a + 1] << 8) | ((uint32_t)src[a + 2] << 16);
-                uint32_t sh = 8u * (a & 3u);
+                uint32_t sh = 8u * ((a + mis) & 3u);
                 w0 = b3 << sh; w1 = sh ? b3 >> (32u - sh) : 0u;
             }
         }
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
             {
                 uint32_t a = r0 + tid, hv = 0xffffu;
                 if (a < Ex) {
-                    uint32_t b3 = __builtin_amdgcn_alignbyte(w1, w0, a & 3u);
+                    uint32_t b3 = __builtin_amdgcn_alignbyte(w1, w0, (a + mis) & 3u);
                     uint32_t h = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
                     if ((h >> 15) == pass) hv = h & 32767u;
                 }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     uint16_t *s_pd = (uint16_t *)(s_lds + ZK_PD_OFF / 4);
     const uint32_t tid = threadIdx.x;
     const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     if ((uint64_t)tile * ZK_TILE >= g.len) return;
     const uint32_t E = g.dict_len + g.len;
     const uint32_t t0 = g.dict_len + tile * ZK_TILE;
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
      * CU's four SIMDs share is what nested predicates would saturate.  Candidates
      * that pass the 3-byte peek are parked and compared in full, together, at the
      * next service point. */
-    const uint32_t nice_match = J.P.nice, max_chain = J.P.chain, qb = max_chain >> 2;
+    const uint32_t nice_match = J.P.nice, max_chain = J.P.chain, qb = max_chain >> 2, max_dist = J.P.max_dist;
     const uint32_t la0 = (uint32_t)a0;
     uint32_t p = t0, cur = t0, best = 2, bdist = 0, qrec = 0, scan3 = 0, cap = 0, nice = 0;
     auto set_scan = [&](uint32_t b) { scan3 = win.load4(p + b - 2u) & 0x00ffffffu; };
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
             if (!fin) {
                 const uint32_t d = dnext;
                 if (kk >= 0 || d == 0 || d >= cur) fin = true;
-                else { cur -= d; fin = p - cur >= ZC_MAX_DIST; }
+                else { cur -= d; fin = p - cur >= max_dist; }
             }
             parked = 0; walking = -1;
             if (fin) {
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
             if (walking == 0 && rank < take) {
                 const uint32_t idx = wcur + rank;
                 ZcMatchState st;
-                if (zc_match_init(win, pd, t0 + idx, E, g.corner, nice_match, st)) {
+                if (zc_match_init(win, pd, t0 + idx, E, g.corner, nice_match, st, max_dist)) {
                     p = st.p; cur = st.cur; kk = -(int32_t)max_chain; best = 2; bdist = 0; qrec = 0;
                     scan3 = st.scan3; cap = st.cap; nice = st.nice;
                     walking = -1;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         /* ---- candidate steps until a quarter of the lanes need service */
         const uint32_t full_now = best >= 3u ? (best | (bdist << 16)) : 0u;   /* best is fixed while walking */
         const uint32_t pout = p - t0;
-        const int32_t lim = (int32_t)(p < ZC_MAX_DIST ? p : ZC_MAX_DIST);      /* stop once the distance reaches this */
+        const int32_t lim = (int32_t)(p < max_dist ? p : max_dist);      /* stop once the distance reaches this */
         /* the loop runs on ac = candidate + (best - 2) - la0, the LDS byte offset of the candidate's bytes best-2..,
          * so that neither the peek address nor the link address nor the distance test needs an addition of its own */
         const uint32_t peek_off = (best - 2u) - la0;
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(64) void k_parse(ZkJob J)
 {
     __shared__ uint2 s_tile[ZK_PARSE_TILE];
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     TileRec rec; rec.g = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.tile = s_tile;
     rec.dict_len = g.dict_len; rec.len = g.len; rec.base = 0xffff0000u; rec.lane = lane;
     GSym sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size; sym.lane = lane;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t t
     __shared__ unsigned long long s_mask[ZK_RESOLVE_TILE / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     const uint32_t i0 = tile * ZK_RESOLVE_TILE;
     if (i0 >= g.len) return;
     const uint32_t tl = g.len - i0 < ZK_RESOLVE_TILE ? g.len - i0 : ZK_RESOLVE_TILE;
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
 {
     __shared__ uint32_t s_tile[ZK_HOP_TILE];
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     const uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;
     uint32_t *hopw = J.hop + (uint64_t)lc * J.P.chunk_size;
     uint32_t *arr = J.arr + (uint64_t)lc * (J.P.chunk_size / 2);
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
     __shared__ uint32_t s_wsum[ZK_EXPAND_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t lc = blockIdx.x;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     const uint32_t E = g.dict_len + g.len, lim = J.P.lit_bufsize - 1;
     const uint32_t H = J.nhop[lc];
     const uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
             B.sym_start = b * lim; B.sym_count = (b + 1 < nb) ? lim : nsym - b * lim;
             B.in_start = in_start; B.in_len = in_end - in_start;
             B.flags = ((b + 1 == nb && g.final) ? ZC_BF_LAST : 0u) |
-                      (in_start >= zc_window_base(p_top, E, ZC_MIN_LOOK) ? ZC_BF_CANSTORE : 0u);
+                      (in_start >= zc_window_base(p_top, E, ZC_MIN_LOOK, J.P.wsize) ? ZC_BF_CANSTORE : 0u);
             B.type = 0; B.bits = b + 1 == nb ? 0u : in_end; B.hdr_bits = 0; B.bit_off = 0;
             blk[b] = B;
         }
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
     const uint32_t tid = threadIdx.x;
     const uint32_t lc = blockIdx.y, j = blockIdx.x;
     if (j >= J.nblk[lc]) return;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     ZcBlock *bp = J.blk + (uint64_t)lc * J.P.max_blocks + j;
     ZcBlock b = *bp;
     if (b.flags & ZC_BF_STORED) return;          /* type 0 already; nothing to count or build */
@@ -656,6 +659,16 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
         }
     }
     __syncthreads();
+    if (tid == 0 && j == 0 && J.chunk0 + lc == 0) {
+        /* detect_data_type on the first block of the call (trees.c:920-921, 1120-1147): 1 + Z_BINARY / Z_TEXT */
+        uint32_t dt_ = 0, n;
+        for (n = 0; n < 32; n++) if (((0xf3ffc07fu >> n) & 1u) && hist[n]) break;
+        if (n == 32) {
+            if (hist[9] || hist[10] || hist[13]) dt_ = 1;
+            else for (n = 32; n < 256; n++) if (hist[n]) { dt_ = 1; break; }
+        }
+        J.err[2] = 1u + dt_;
+    }
     for (uint32_t i = tid; i < ZC_L_CODES; i += ZK_PLAN_THREADS) lt.freq[i] = (uint16_t)(i == ZC_END_BLOCK ? 1u : hist[i]);
     if (tid < ZC_D_CODES) dt.freq[tid] = (uint16_t)hist[288 + tid];
     __syncthreads();
@@ -683,14 +696,18 @@ __global__ void k_layout(ZkJob J)
 {
     uint32_t lc = blockIdx.x * blockDim.x + threadIdx.x;
     if (lc >= J.nchunks) return;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     ZcBlock *base = J.blk + (uint64_t)lc * J.P.max_blocks;
     uint64_t sync = 0;
     /* a non-final chunk that is the last of a call without finish still ends on a sync marker */
     const uint32_t pb = (J.chunk0 + lc == 0) ? J.prime_bits : 0u;
     if (pb) atomicOr(&J.out32[0], J.prime_val);
-    J.chunk_bytes[lc] = zc_layout_chunk([&](uint32_t i) { return base + i; }, J.nblk[lc], g.final, &sync, pb);
+    const bool call_end = J.chunk0 + lc == J.last_chunk;
+    uint32_t left = 0;
+    J.chunk_bytes[lc] = zc_layout_chunk([&](uint32_t i) { return base + i; }, J.nblk[lc], g.final, &sync, pb,
+                                        call_end ? J.P.tail : (uint32_t)ZC_TAIL_SYNC, &left);
     J.sync_bit[lc] = sync;
+    if (call_end) J.err[3] = left;
 }
 
 __global__ __launch_bounds__(1024) void k_scan(ZkJob J)
@@ -745,14 +762,18 @@ __global__ __launch_bounds__(ZK_EMIT_THREADS) void k_emit(ZkJob J)
     if (*J.err) return;
     const uint32_t nb = J.nblk[lc];
     if (j > nb) return;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     const uint64_t cbit = J.chunk_off[J.chunk0 + lc] * 8ull;
     uint32_t *out32 = J.out32;
-    if (j == nb) {                                /* Z_SYNC_FLUSH marker: 000, pad, 00 00 FF FF */
+    if (j == nb) {
+        const uint32_t tail = J.chunk0 + lc == J.last_chunk ? J.P.tail : (uint32_t)ZC_TAIL_SYNC;
         if (!g.final && tid == 0) {
-            uint64_t bit = cbit + J.sync_bit[lc] + 3;
-            bit = (bit + 7) & ~7ull;
-            g_or_bits(out32, bit + 16, 0xffffu, 16);
+            if (tail == ZC_TAIL_SYNC) {               /* Z_SYNC_FLUSH marker: 000, pad, 00 00 FF FF */
+                uint64_t bit = cbit + J.sync_bit[lc] + 3;
+                bit = (bit + 7) & ~7ull;
+                g_or_bits(out32, bit + 16, 0xffffu, 16);
+            } else if (tail == ZC_TAIL_ALIGN)         /* _tr_align: STATIC_TREES << 1 in 3 bits, then the all-zero code of END_BLOCK */
+                g_or_bits(out32, cbit + J.sync_bit[lc], 2u, 10);
         }
         return;
     }
@@ -931,6 +952,10 @@ struct zamd_engine {
     int serialize;                  /* batches are cut as for nstreams in flight but issued to one stream: every kernel alone on the GPU */
     int spec_match;                 /* follow the parse (k_spec) instead of searching every position (k_match) */
     uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
+    int wbits;                        /* windowBits of the following deflate calls (9..15) */
+    uint32_t tail_mode;               /* ZC_TAIL_* for the next deflate call only */
+    uint32_t pend_bits, pend_val;     /* bits the last call left behind its last complete byte */
+    int data_type;                    /* detect_data_type of the last call's first block, or Z_UNKNOWN (2) */
     int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
     uint64_t ws_budget;
     uint64_t *d_total; uint32_t *d_err; uint32_t last_fallback_hops;
@@ -995,6 +1020,7 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     memset((void *)e, 0, sizeof *e);
     for (int i = 0; i < ZE_STREAMS; i++) e->ws[i] = ZeWorkspace();
     e->nstreams = 4;                 /* one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4) */
+    e->wbits = 15; e->data_type = 2;
     e->spec_match = getenv("ZAMD_MATCH_SPEC") ? 1 : 0;
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->serialize = getenv("ZAMD_SERIALIZE") ? 1 : 0;
@@ -1057,6 +1083,30 @@ extern "C" int zamd_engine_set_streams(zamd_engine *e, int nstreams, int seriali
     return ZAMD_OK;
 }
 
+extern "C" int zamd_engine_window_bits(zamd_engine *e, int window_bits)
+{
+    if (!e || window_bits < 9 || window_bits > 15) return ZAMD_STREAM_ERROR;
+    e->wbits = window_bits;
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_engine_tail(zamd_engine *e, int mode)
+{
+    if (!e || mode < 0 || mode > 2) return ZAMD_STREAM_ERROR;
+    e->tail_mode = (uint32_t)mode;
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_engine_pending_bits(zamd_engine *e, int *bits, int *value)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    if (bits) *bits = (int)e->pend_bits;
+    if (value) *value = (int)e->pend_val;
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_engine_data_type(zamd_engine *e) { return e ? e->data_type : 2; }
+
 extern "C" int zamd_engine_prime(zamd_engine *e, int bits, int value)
 {
     if (!e || bits < 0 || bits > 7) return ZAMD_STREAM_ERROR;
@@ -1070,11 +1120,12 @@ extern "C" uint64_t zamd_deflate_bound(uint64_t n, uint32_t chunk_size, int mem_
     uint64_t chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
     /* worst case: every block stored (5 bytes each, and never larger than the
      * coded form + 4) plus the sync marker / final padding per chunk */
-    uint64_t b = n + chunks * ((uint64_t)max_blocks_for(chunk_size, mem_level) * 5 + 16) + 64;
+    /* level 0 with a small window cuts a stored block every MAX_DIST bytes (deflate.c:1607-1609): 5 bytes per 250 at windowBits 9 */
+    uint64_t b = n + n / 50 + chunks * ((uint64_t)max_blocks_for(chunk_size, mem_level) * 5 + 16) + 64;
     return (b + 15) & ~15ull;
 }
 
-static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint32_t chunk_size)
+static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint32_t chunk_size, int wbits = 15)
 {
     static const uint16_t cfg[10][4] = {{0, 0, 0, 0}, {4, 4, 8, 4}, {4, 5, 16, 8}, {4, 6, 32, 32}, {4, 4, 16, 16},
                                         {8, 16, 32, 32}, {8, 16, 128, 128}, {8, 32, 128, 256}, {32, 128, 258, 1024}, {32, 258, 258, 4096}};
@@ -1091,6 +1142,12 @@ static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint
     P.parser = strategy == ZC_STRAT_HUFF ? ZC_PARSE_HUFF : strategy == ZC_STRAT_RLE ? ZC_PARSE_RLE : level == 0 ? ZC_PARSE_STORED : level <= 3 ? ZC_PARSE_FAST : ZC_PARSE_SLOW;
     P.chunk_size = chunk_size;
     P.max_blocks = max_blocks_for(chunk_size, mem_level);
+    P.wsize = 1u << wbits; P.max_dist = P.wsize - ZC_MIN_LOOK;
+    if (level == 0) {       /* deflate_stored ends a block at max_block bytes or as soon as it spans MAX_DIST (deflate.c:1597-1609) */
+        uint32_t mb = P.lit_bufsize * 4u - 5u; if (mb > 0xffffu) mb = 0xffffu; if (mb > P.max_dist) mb = P.max_dist;
+        const uint32_t nb = chunk_size / mb + 4u;
+        if (nb > P.max_blocks) P.max_blocks = nb;
+    }
     return ZAMD_OK;
 }
 
@@ -1111,11 +1168,13 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
                                       void *d_out, uint64_t out_cap, uint64_t *d_chunk_off, uint64_t *total_out)
 {
     if (!e || !d_out || (!d_in && n)) return ZAMD_STREAM_ERROR;
-    if (head_dict_len > ZC_WSIZE || (head_dict_len & 15u)) return ZAMD_STREAM_ERROR;
     if (((uintptr_t)d_in & 15u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
     ZcParams P;
-    int rc = fill_params(P, level, strategy, mem_level, chunk_size);
+    int rc = fill_params(P, level, strategy, mem_level, chunk_size, e->wbits);
     if (rc) return rc;
+    if (head_dict_len > P.wsize) return ZAMD_STREAM_ERROR;
+    P.tail = e->tail_mode; e->tail_mode = ZC_TAIL_SYNC;
+    e->pend_bits = 0; e->pend_val = 0; e->data_type = 2;
     if (e->tuned && level != 0) {
         P.good = e->tune[0]; P.lazy = e->tune[1]; P.nice = e->tune[2]; P.chain = e->tune[3];
         /* levels 1-3 compare the candidates of a walk one per lane */
@@ -1162,8 +1221,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         ZkJob J; memset(&J, 0, sizeof J);
         J.in = (const uint8_t *)d_in - head_dict_len; J.n = n + head_dict_len; J.head = head_dict_len; J.chunk0 = (uint64_t)bi * batch;
         J.nchunks = (uint32_t)((total_chunks - J.chunk0) < batch ? (total_chunks - J.chunk0) : batch);
-        J.finish = finish; J.P = P; J.prime_bits = prime_bits; J.prime_val = prime_val;
-        ZcChunkGeom g0 = zc_geom(J.n, chunk_size, J.chunk0, finish, J.head);
+        J.finish = finish; J.P = P; J.prime_bits = prime_bits; J.prime_val = prime_val; J.last_chunk = total_chunks - 1;
+        ZcChunkGeom g0 = zc_geom(J.n, chunk_size, J.chunk0, finish, J.head, P.wsize);
         J.pdist = w.pdist; J.pdist_base = g0.dstart; J.pdist_len = w.pdist_len;
         J.rec = w.rec; J.rec_base = head_dict_len + J.chunk0 * chunk_size;
         J.sym = w.sym; J.hop = w.hop; J.nhop = w.nhop; J.arr = (uint32_t *)w.rec; J.blk = w.blk; J.tab = w.tab; J.nblk = w.nblk; J.nsym = w.nsym;
@@ -1234,7 +1293,16 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     uint64_t total = 0; uint32_t err = 0;
     HIPCHK(hipMemcpy(&total, e->d_total, 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&err, e->d_err, 4, hipMemcpyDeviceToHost));
-    { uint32_t nf = 0; HIPCHK(hipMemcpy(&nf, e->d_err + 1, 4, hipMemcpyDeviceToHost)); e->last_fallback_hops = nf; }
+    uint32_t ev[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(ev, e->d_err, 16, hipMemcpyDeviceToHost));
+    e->last_fallback_hops = ev[1];
+    e->data_type = ev[2] ? (int)ev[2] - 1 : 2;
+    if (!finish && P.tail != ZC_TAIL_SYNC && ev[3] && !(err & ~0u)) {
+        /* the bits behind the last complete byte wait for the next call, as they would in bi_buf */
+        uint8_t last = 0;
+        HIPCHK(hipMemcpy(&last, (const uint8_t *)d_out + total, 1, hipMemcpyDeviceToHost));
+        e->pend_bits = ev[3]; e->pend_val = last & ((1u << ev[3]) - 1u);
+    }
     for (int k = 0; k < 12; k++) { e->t_ms[k] = 0; e->t_n[k] = 0; }
     for (int i = 0; i < e->n_tm; i++) { float ms = 0; if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->t_ms[e->tm[i].which] += ms; e->t_n[e->tm[i].which]++; } }
     { float ms = 0; if (hipEventElapsedTime(&ms, e->ev_call[0], e->ev_call[1]) == hipSuccess) { e->t_ms[6] = ms; e->t_n[6] = 1; } }
@@ -1263,7 +1331,7 @@ extern "C" int64_t zamd_debug_dump(zamd_engine *e, int what, uint32_t chunk, voi
 {
     if (!e || !e->have_last || chunk >= e->last_job.nchunks) return ZAMD_STREAM_ERROR;
     const ZkJob &J = e->last_job;
-    ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + chunk, J.finish, J.head);
+    ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + chunk, J.finish, J.head, J.P.wsize);
     uint64_t cnt = 0; const void *src = nullptr; size_t esz = 0;
     uint32_t nb = 0, ns = 0;
     hipMemcpy(&nb, J.nblk + chunk, 4, hipMemcpyDeviceToHost);

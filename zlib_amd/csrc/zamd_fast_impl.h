@@ -34,6 +34,7 @@ struct ZkFastCtx {
     uint16_t *prev_l;             /* LDS: prev[] of the newest ZF_NEAR window indices */
     uint16_t *prev_g, *fhead;     /* global: all of prev[] (32768 entries), head[] */
     uint32_t hshift, hmask, hsize, nice, chain, lane;
+    uint32_t wsize, wmask, near, max_dist;    /* window size (deflate.c:284), its mask, LDS-resident links (<= wsize), wsize - MIN_LOOKAHEAD */
     uint32_t q0;                  /* first position of the current batch */
     uint32_t h_cur, hv_cur, h_nxt, hv_nxt;   /* per lane: hash and head entry of q0 + lane, q0 + 64 + lane */
 
@@ -74,7 +75,7 @@ struct ZkFastCtx {
         const uint32_t e = __builtin_amdgcn_readlane(hv_cur, k);
         hv_cur = (lane > k && h_cur == hq) ? wi : hv_cur;
         hv_nxt = h_nxt == hq ? wi : hv_nxt;
-        if (lane == 0) { prev_l[wi & (ZF_NEAR - 1u)] = (uint16_t)e; prev_g[wi & 32767u] = (uint16_t)e; fhead[hq] = (uint16_t)wi; }
+        if (lane == 0) { prev_l[wi & (near - 1u)] = (uint16_t)e; prev_g[wi & wmask] = (uint16_t)e; fhead[hq] = (uint16_t)wi; }
         return e;
     }
     __device__ __forceinline__ void rebase(uint16_t *t, uint32_t n)
@@ -85,7 +86,7 @@ struct ZkFastCtx {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t lo = v[j] & 0xffffu, hi = v[j] >> 16;
-                v[j] = (lo >= 32768u ? lo - 32768u : 0u) | ((hi >= 32768u ? hi - 32768u : 0u) << 16);
+                v[j] = (lo >= wsize ? lo - wsize : 0u) | ((hi >= wsize ? hi - wsize : 0u) << 16);
             }
             *(uint4 *)(t + i) = make_uint4(v[0], v[1], v[2], v[3]);
         }
@@ -94,10 +95,10 @@ struct ZkFastCtx {
     {
         __threadfence_block();
         rebase(fhead, hsize);
-        rebase(prev_g, 32768u);
-        for (uint32_t i = lane; i < ZF_NEAR; i += 64) { const uint32_t m = prev_l[i]; prev_l[i] = (uint16_t)(m >= 32768u ? m - 32768u : 0u); }
-        hv_cur = hv_cur >= 32768u ? hv_cur - 32768u : 0u;
-        hv_nxt = hv_nxt >= 32768u ? hv_nxt - 32768u : 0u;
+        rebase(prev_g, wsize);
+        for (uint32_t i = lane; i < near; i += 64) { const uint32_t m = prev_l[i]; prev_l[i] = (uint16_t)(m >= wsize ? m - wsize : 0u); }
+        hv_cur = hv_cur >= wsize ? hv_cur - wsize : 0u;
+        hv_nxt = hv_nxt >= wsize ? hv_nxt - wsize : 0u;
         __threadfence_block();
     }
     /* longest_match (deflate.c:1148-1289) with prev_length 2: the chain is walked
@@ -106,13 +107,13 @@ struct ZkFastCtx {
      * longer wins, stop at the first one that reaches nice_match. */
     __device__ __forceinline__ void longest(uint32_t p, uint32_t B, uint32_t cur, uint32_t look, uint32_t *mlen, uint32_t *mdist)
     {
-        const uint32_t sw = p - B, limit = sw > ZC_MAX_DIST ? sw - ZC_MAX_DIST : 0u;
+        const uint32_t sw = p - B, limit = sw > max_dist ? sw - max_dist : 0u;
         const uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH, nice_eff = nice < look ? nice : look;
         uint32_t candv = 0, n = 0;
         do {
             candv = lane == n ? cur : candv;
             n++;
-            cur = sw - cur < ZF_NEAR ? zi_uni(prev_l[cur & (ZF_NEAR - 1u)]) : zi_uni(prev_g[cur & 32767u]);
+            cur = sw - cur < near ? zi_uni(prev_l[cur & (near - 1u)]) : zi_uni(prev_g[cur & wmask]);
         } while (cur > limit && n < chain);
         uint32_t len = 0;
         if (lane < n) {
@@ -152,12 +153,13 @@ __global__ __launch_bounds__(64) void k_fast(ZkJob J)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_prev[ZF_NEAR];
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     ZkFastCtx cx;
     cx.b = J.in + g.dstart; cx.readable = J.n - g.dstart; cx.E = g.dict_len + g.len;
     cx.prev_l = s_prev; cx.fhead = J.fhead + (uint64_t)lc * ZF_ROW; cx.prev_g = cx.fhead + 65536u;
     cx.hshift = J.P.hash_shift; cx.hmask = J.P.hash_mask; cx.hsize = J.P.hash_mask + 1u;
     cx.nice = J.P.nice; cx.chain = J.P.chain; cx.lane = lane;
+    cx.wsize = J.P.wsize; cx.wmask = J.P.wsize - 1u; cx.near = J.P.wsize < ZF_NEAR ? J.P.wsize : ZF_NEAR; cx.max_dist = J.P.max_dist;
     for (uint32_t i = lane; i < ZF_NEAR; i += 64) s_prev[i] = 0;
     __syncthreads();
     cx.start_batches(0);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
     uint16_t *s_pd = (uint16_t *)(s_lds + ZK_SPEC_WIN / 4);
     const uint32_t tid = threadIdx.x;
     const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head);
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     if ((uint64_t)tile * ZK_TILE >= g.len) return;
     const uint32_t E = g.dict_len + g.len;
     const uint32_t t0 = g.dict_len + tile * ZK_TILE;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
     LdsWin win; win.w = s_win; win.a0 = (uint32_t)a0;
     LdsPd pd; pd.pd = s_pd; pd.a0 = (uint32_t)a0;
     uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;      /* index = a-coordinate - dict_len */
-    const uint32_t nice_match = J.P.nice, max_chain = J.P.chain, good = J.P.good, lazy = J.P.lazy;
+    const uint32_t nice_match = J.P.nice, max_chain = J.P.chain, good = J.P.good, lazy = J.P.lazy, max_dist = J.P.max_dist;
     const uint32_t qbudget = (max_chain >> 2) ? (max_chain >> 2) : 0x7fffffffu;   /* zero wraps in the reference's do-while */
     const bool filt = J.P.strategy == ZC_STRAT_FILTERED;
     const uint32_t la0 = (uint32_t)a0;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
 
     auto start_walk = [&](uint32_t q, uint32_t pl) -> bool {
         ZcMatchState ms;
-        if (!zc_match_init(win, pd, q, E, g.corner, nice_match, ms)) return false;
+        if (!zc_match_init(win, pd, q, E, g.corner, nice_match, ms, max_dist)) return false;
         if (pl >= ms.cap) return false;
         p = q; cur = ms.cur; cap = ms.cap; nice = ms.nice; best = pl; plen = pl; bdist = 0;
         scan3 = pl > 2u ? (win.load4(q + pl - 2u) & 0x00ffffffu) : ms.scan3;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
             if (!fin) {
                 uint32_t d = pd(cur);
                 if (kk >= 0 || d == 0 || d >= cur) fin = true;
-                else { cur -= d; fin = p - cur >= ZC_MAX_DIST; }
+                else { cur -= d; fin = p - cur >= max_dist; }
             }
             parked = 0; walking = fin ? 0 : -1;
         }
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
         /* ---- candidate steps until enough lanes need service */
         const uint32_t live = (uint32_t)__popcll(__ballot(st != ZS_DONE));
         const uint32_t thr = live / 2u < (uint32_t)THRESH ? (live / 2u ? live / 2u : 1u) : (uint32_t)THRESH;
-        const int32_t lim = (int32_t)(p < ZC_MAX_DIST ? p : ZC_MAX_DIST);      /* stop once the distance reaches this */
+        const int32_t lim = (int32_t)(p < max_dist ? p : max_dist);      /* stop once the distance reaches this */
         const uint32_t peek_off = (best - 2u) - la0;
         const uint16_t *link = s_pd - la0;
         uint32_t c = cur;                     /* candidate */

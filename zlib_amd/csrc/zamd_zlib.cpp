@@ -201,11 +201,13 @@ void write_header(z_streamp strm, DState *s) {     // deflate.c:690-867
 
 // Compress `n` bytes at `src` (host) as chunks primed with the stream's history;
 // append the result to s->out and fold the bytes into strm->adler.
-int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int finish) {
+// `tail`: how the output ends when finish == 0 (ZAMD_TAIL_*: sync marker, _tr_align, nothing).
+int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int finish, int tail = ZAMD_TAIL_SYNC) {
     std::lock_guard<std::mutex> lk(g_gpu.mu);
     zamd_engine *e = engine_locked();
     if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
-    uint32_t head = s->hist_len & ~15u;            // the engine takes its dictionary in multiples of 16 bytes: drop the oldest few
+    const uint32_t wsize = 1u << s->w_bits;
+    uint32_t head = s->hist_len;
     uint64_t bound = zamd_deflate_bound(n, s->chunk_size, s->mem_level);
     if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, HIST + n + 64) != Z_OK) return Z_MEM_ERROR;
     if (grow(e, &g_gpu.d_out, &g_gpu.out_cap, bound + 64) != Z_OK) return Z_MEM_ERROR;
@@ -217,7 +219,9 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     uint64_t total = 0;
     if (rc == 0) {
         if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+        if (rc == 0) rc = zamd_engine_window_bits(e, s->w_bits);
         if (rc == 0 && s->prime_bits) { rc = zamd_engine_prime(e, (int)s->prime_bits, (int)s->prime_val); s->prime_bits = 0; s->prime_val = 0; }
+        if (rc == 0 && !finish && tail != ZAMD_TAIL_SYNC) { rc = zamd_engine_tail(e, tail); s->index_ok = false; }
         const uint64_t nch = n ? (n + s->chunk_size - 1) / s->chunk_size : 1;
         uint64_t *d_tab = nullptr;
         if (rc == 0 && s->index_on && s->index_ok) {
@@ -238,6 +242,15 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
             }
         }
         if (s->tuned) zamd_engine_tune(e, 0, 0, 0, 0);      // the engine is shared by all streams
+        zamd_engine_window_bits(e, 15);
+        if (rc == 0) {
+            // bits behind the last whole byte stay in the bit buffer (bi_flush, trees.c:1169-1181): they lead the next block
+            int pb = 0, pv = 0;
+            zamd_engine_pending_bits(e, &pb, &pv);
+            s->prime_bits = (uint32_t)pb; s->prime_val = (uint32_t)pv;
+            // strm->data_type comes from the first block flushed at level > 0 (trees.c:920-921)
+            if (strm->data_type == Z_UNKNOWN) { int dt = zamd_engine_data_type(e); if (dt != Z_UNKNOWN) strm->data_type = dt; }
+        }
     }
     tr.lap("deflate");
     if (rc == 0 && s->wrap && n) {
@@ -262,12 +275,12 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     if (rc != 0) return rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : (rc == ZAMD_BUF_ERROR ? Z_BUF_ERROR : Z_STREAM_ERROR);
     // history for the next batch = last 32 KiB of everything compressed since the last reset
     s->since_reset += n;
-    if (n >= HIST) {
-        s->hist.assign(src + n - HIST, src + n);
-        s->hist_len = HIST;
+    if (n >= wsize) {
+        s->hist.assign(src + n - wsize, src + n);
+        s->hist_len = wsize;
     } else if (n) {
         s->hist.insert(s->hist.end(), src, src + n);
-        if (s->hist.size() > HIST) s->hist.erase(s->hist.begin(), s->hist.end() - HIST);
+        if (s->hist.size() > wsize) s->hist.erase(s->hist.begin(), s->hist.end() - wsize);
         s->hist_len = (uint32_t)s->hist.size();
     }
     return Z_OK;
@@ -276,7 +289,8 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
 void reset_history(DState *s) { s->hist.clear(); s->hist_len = 0; s->since_reset = 0; }
 
 int finish_batch(z_streamp strm, DState *s, int flush) {
-    int rc = run_batch(strm, s, s->in.data(), s->in.size(), flush == Z_FINISH);
+    const int tail = flush == Z_PARTIAL_FLUSH ? ZAMD_TAIL_ALIGN : flush == Z_BLOCK ? ZAMD_TAIL_NONE : ZAMD_TAIL_SYNC;   // deflate.c:923-945
+    int rc = run_batch(strm, s, s->in.data(), s->in.size(), flush == Z_FINISH, tail);
     if (rc != Z_OK) return rc;
     s->in.clear();
     if (flush == Z_FULL_FLUSH) reset_history(s);          // deflate.c:930-937: forget the history
@@ -326,9 +340,9 @@ int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int mem
     if (memLevel < 1 || memLevel > 9 || method != Z_DEFLATED || windowBits < 8 || windowBits > 15 ||
         level < 0 || level > 9 || strategy < 0 || strategy > Z_FIXED)
         return Z_STREAM_ERROR;
-    // The engine implements the 32 KiB window only; level 0 with Z_HUFFMAN_ONLY / Z_RLE overruns the
-    // reference's own pending buffer (trees.c:1224) and is refused.
-    if (windowBits != 15 || (level == 0 && (strategy == Z_HUFFMAN_ONLY || strategy == Z_RLE))) { strm->msg = "parameter not supported by the GPU engine"; return Z_STREAM_ERROR; }
+    if (windowBits == 8) windowBits = 9;      // until 256-byte window bug fixed, deflate.c:276
+    // level 0 with Z_HUFFMAN_ONLY / Z_RLE overruns the reference's own pending buffer (trees.c:1224) and is refused.
+    if (level == 0 && (strategy == Z_HUFFMAN_ONLY || strategy == Z_RLE)) { strm->msg = "parameter not supported by the GPU engine"; return Z_STREAM_ERROR; }
     void *mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(DState));
     if (mem == Z_NULL) return Z_MEM_ERROR;
     DState *s = new (mem) DState();
@@ -396,8 +410,9 @@ int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
         uLong id = adler32(strm->adler, dictionary, dictLength);
         strm->adler = id; s->dictid = (uint32_t)id; s->have_dict = true;
     }
-    // the window keeps the last 32 KiB (deflate.c:347-356); it primes the first chunk
-    uInt keep = dictLength > HIST ? HIST : dictLength;
+    // the window keeps the last w_size bytes (deflate.c:347-356); they prime the first chunk
+    const uInt wsize = 1u << s->w_bits;
+    uInt keep = dictLength > wsize ? wsize : dictLength;
     s->hist.assign(dictionary + (dictLength - keep), dictionary + dictLength);
     s->hist_len = keep;
     return Z_OK;
