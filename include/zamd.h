@@ -124,6 +124,17 @@ int zamd_checksums_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t ch
 int zamd_adler32_dev(zamd_engine *e, uint32_t adler, const void *d_in, uint64_t n, uint32_t *result);
 int zamd_crc32_dev(zamd_engine *e, uint32_t crc, const void *d_in, uint64_t n, uint32_t *result);
 
+/*
+ * zamd_adler32_dev and zamd_crc32_dev in one call that allocates nothing: no counterpart in the reference; it is for
+ * callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * The per-slice partial checksums go to a fixed array inside the library's code object (128 KiB per GPU, held until the
+ * process ends) instead of a hipMalloc'ed buffer, and are folded on the GPU: d_result (DEVICE memory, 2 x uint32) receives
+ * adler32(adler, d_in, n) and crc32(crc, d_in, n).  n is at most 16 GiB (16384 slices of 1 MiB): larger inputs are
+ * refused with ZAMD_BUF_ERROR and a message on stderr.  Every call on a GPU shares that GPU's array: calls that overlap
+ * on one GPU race.  Blocks the calling thread until the result is in d_result.
+ */
+int zamd_checksums_noalloc_dev(zamd_engine *e, uint32_t adler, uint32_t crc, const void *d_in, uint64_t n, uint32_t *d_result);
+
 /* adler32_combine (adler32.c:136-162) and crc32_combine (crc32.c:327-408). */
 uint32_t zamd_adler32_combine(uint32_t adler1, uint32_t adler2, int64_t len2);
 uint32_t zamd_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);

@@ -79,6 +79,8 @@ def load_library() -> C.CDLL:
     lib.zamd_adler32_dev.restype = i32
     lib.zamd_crc32_dev.argtypes = [vp, u32, vp, u64, C.POINTER(u32)]
     lib.zamd_crc32_dev.restype = i32
+    lib.zamd_checksums_noalloc_dev.argtypes = [vp, u32, u32, vp, u64, vp]
+    lib.zamd_checksums_noalloc_dev.restype = i32
     lib.zamd_adler32_combine.argtypes = [u32, u32, C.c_int64]
     lib.zamd_adler32_combine.restype = u32
     lib.zamd_crc32_combine.argtypes = [u32, u32, C.c_int64]

@@ -928,6 +928,68 @@ __global__ __launch_bounds__(256) void k_checksum(const uint8_t *in, uint64_t n,
     }
 }
 
+/* adler32_combine (adler32.c:136-162) for kernels and host alike */
+__device__ __host__ inline uint32_t zk_adler_combine(uint32_t a1, uint32_t a2, uint64_t len2)
+{
+    const uint32_t B = 65521u;
+    uint32_t rem = (uint32_t)(len2 % B), s1 = a1 & 0xffffu, s2 = (uint32_t)(((uint64_t)rem * s1) % B);
+    s1 += (a2 & 0xffffu) + B - 1;
+    s2 += (a1 >> 16) + (a2 >> 16) + B - rem;
+    if (s1 >= B) s1 -= B;
+    if (s1 >= B) s1 -= B;
+    if (s2 >= (B << 1)) s2 -= (B << 1);
+    if (s2 >= B) s2 -= B;
+    return s1 | (s2 << 16);
+}
+
+/* ------------------------------------------------------------------ whole-buffer checksums without any allocation
+ * Per-slice partial checksums go to a fixed device array of the code object instead of a buffer from hipMalloc, and
+ * are folded on the device, so that the call neither allocates nor copies to the host.  One array per GPU, shared by
+ * every call on that GPU: calls that overlap on one GPU race. */
+#define ZNA_SLICE      (1u << 20)
+#define ZNA_MAX_SLICES 16384u                     /* inputs of up to 16 GiB */
+static __device__ __align__(256) uint32_t scratch[2u * ZNA_MAX_SLICES];   /* [0, MAX): adler32 per slice, [MAX, 2 MAX): crc32 per slice */
+#define ZNA_MAX_DEVICES 64
+static uint32_t *g_na_scratch[ZNA_MAX_DEVICES];   /* device address of `scratch` on each GPU, from hipGetSymbolAddress */
+
+/* Folds the per-slice values (slices of `slice` bytes, the last one shorter) onto the seeds: one workgroup; every
+ * thread folds a run of consecutive slices, then the runs are folded pairwise in LDS. */
+__global__ __launch_bounds__(1024) void k_ck_fold(const uint32_t *part_a, const uint32_t *part_c, uint32_t nslices, uint64_t n, uint32_t slice,
+                                                  uint32_t seed_a, uint32_t seed_c, uint32_t *out2)
+{
+    __shared__ uint32_t s_a[1024], s_c[1024];
+    __shared__ unsigned long long s_len[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (nslices + 1023u) / 1024u;
+    uint32_t a = 1u, c = 0u; unsigned long long len = 0;      /* checksums of the empty string */
+    for (uint32_t k = 0; k < per; k++) {
+        const uint32_t i = tid * per + k;
+        if (i >= nslices) break;
+        const unsigned long long off = (unsigned long long)i * slice;
+        const unsigned long long l = n - off < slice ? n - off : slice;
+        a = zk_adler_combine(a, part_a[i], l);
+        c = gf2_mul(gf2_xpow8n(l, c_crc.x2n), c) ^ part_c[i];
+        len += l;
+    }
+    s_a[tid] = a; s_c[tid] = c; s_len[tid] = len;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        if ((tid & (2 * d - 1)) == 0) {
+            const unsigned long long l2 = s_len[tid + d];
+            if (l2) {
+                s_a[tid] = zk_adler_combine(s_a[tid], s_a[tid + d], l2);
+                s_c[tid] = gf2_mul(gf2_xpow8n(l2, c_crc.x2n), s_c[tid]) ^ s_c[tid + d];
+                s_len[tid] += l2;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out2[0] = zk_adler_combine(seed_a, s_a[0], s_len[0]);
+        out2[1] = gf2_mul(gf2_xpow8n(s_len[0], c_crc.x2n), seed_c) ^ s_c[0];
+    }
+}
+
 /* ------------------------------------------------------------------ host side */
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { fprintf(stderr, "zamd: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(_e), __FILE__, __LINE__); return ZAMD_HIP_ERROR(_e); } } while (0)
 
@@ -1036,6 +1098,12 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     HIPCHK(hipMalloc((void **)&e->d_err, 16));       /* [0] error flags, [1] hops k_hop had to search itself */
     crc_host_init();
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_crc), &h_crc, sizeof h_crc));
+    /* the fixed scratch array of the allocation-free checksum call: every GPU has its own copy at its own address */
+    if (device >= 0 && device < ZNA_MAX_DEVICES && !g_na_scratch[device]) {
+        uint32_t *p = nullptr;
+        HIPCHK(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        g_na_scratch[device] = p;
+    }
     e->cap_tm = 512; e->tm = (zamd_engine::Tm *)calloc((size_t)e->cap_tm, sizeof(zamd_engine::Tm));
     for (int i = 0; i < e->cap_tm; i++) { HIPCHK(hipEventCreate(&e->tm[i].a)); HIPCHK(hipEventCreate(&e->tm[i].b)); }
     *out = e;
@@ -1406,6 +1474,27 @@ static int whole_checksum(zamd_engine *e, const void *d_in, uint64_t n, int want
     }
     free(h);
     *result = acc;
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_checksums_noalloc_dev(zamd_engine *e, uint32_t adler, uint32_t crc, const void *d_in, uint64_t n, uint32_t *d_result)
+{
+    if (!e || !d_result || (!d_in && n)) return ZAMD_STREAM_ERROR;
+    const uint64_t nslices = (n + ZNA_SLICE - 1) / ZNA_SLICE;
+    if (nslices > ZNA_MAX_SLICES) {
+        fprintf(stderr, "zamd_checksums_noalloc_dev: %llu bytes exceed the limit of %llu bytes of the fixed scratch array\n",
+                (unsigned long long)n, (unsigned long long)ZNA_MAX_SLICES * ZNA_SLICE);
+        return ZAMD_BUF_ERROR;
+    }
+    if (e->device < 0 || e->device >= ZNA_MAX_DEVICES || !g_na_scratch[e->device]) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    uint32_t *part = g_na_scratch[e->device];       /* the device address, never the host-side name of the array */
+    hipStream_t s = e->st[0];
+    if (nslices)
+        hipLaunchKernelGGL(k_checksum, dim3((uint32_t)nslices), dim3(256), 0, s, (const uint8_t *)d_in, n, ZNA_SLICE, part, part + ZNA_MAX_SLICES);
+    hipLaunchKernelGGL(k_ck_fold, dim3(1), dim3(1024), 0, s, part, part + ZNA_MAX_SLICES, (uint32_t)nslices, n, ZNA_SLICE, adler, crc, d_result);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
     return ZAMD_OK;
 }
 
