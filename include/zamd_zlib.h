@@ -213,6 +213,10 @@ int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_ch
                                                              /* after inflateInit/Reset: the index of the deflate data that
                                                                 follows; inflate() then places whole chunks in one pass.  A
                                                                 hint that does not fit the data is dropped, not trusted */
+/* adler32() and crc32() (zlib.h:1569-1617) have no way to report a failure, and this library can fail where the
+ * reference cannot (no GPU, no device memory): such a call writes a line to stderr, hands its running value back
+ * unchanged and leaves its error code here.  Returns 0 or that code, and clears it.  No counterpart in the reference. */
+int zamd_z_last_error(void);
 /* The same index kept in a gzip file: gzopen(path, "wbI") (or ZAMD_GZ_INDEX=1) appends it as empty gzip members
  * that every gzip reader skips; gzopen for reading finds and uses it (ZAMD_GZ_INDEX=0: ignores it). */
 typedef struct zamd_gz_index { unsigned long long member_offset; unsigned n_chunks; unsigned *pairs; } zamd_gz_index;

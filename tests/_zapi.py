@@ -242,3 +242,60 @@ def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUS
     totals = (s.total_in, s.total_out, s.adler)
     assert l.inflateEnd(C.byref(s)) == 0
     return rc, bytes(out), msg, n - pos, totals
+
+
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libzref.so")
+
+
+def ref_lib():
+    """The unmodified reference build (oracle/_ref/libzref.so), or None where it was not built.  A checker only."""
+    if not os.path.exists(REF_LIB):
+        return None
+    # Python's own zlib module has the system libz in the process: the reference build must bind its internal calls to itself
+    l = C.CDLL(REF_LIB, mode=os.RTLD_LOCAL | os.RTLD_DEEPBIND)
+    P = C.POINTER(ZStream)
+    l.inflateInit2_.argtypes = [P, C.c_int, C.c_char_p, C.c_int]
+    l.inflate.argtypes = [P, C.c_int]
+    l.inflateEnd.argtypes = [P]
+    return l
+
+
+def inf_loop(l, hexs, step, win, length, pieces=None):
+    """The loop of the reference's inf() harness (test/infcover.c:284-347): the input goes in `step` bytes at a time
+    (0 = all at once; `pieces` = explicit piece sizes instead), every inflate() call gets a fresh output buffer of
+    `length` bytes.  Returns (return codes of all calls, output of all calls, last msg), or the init error."""
+    data = bytes.fromhex("".join("%02x" % int(t, 16) for t in hexs.split())) if isinstance(hexs, str) else bytes(hexs)
+    s = ZStream()
+    rc = l.inflateInit2_(C.byref(s), win, VERSION, SZ)
+    if rc != Z_OK:
+        return [rc], b"", None
+    src = C.create_string_buffer(data, max(len(data), 1))
+    obuf = C.create_string_buffer(max(length, 1))
+    have = len(data)
+    sizes = list(pieces) if pieces else None
+    if step == 0 or step > have:
+        step = have
+    nxt = sizes.pop(0) if sizes else step
+    s.next_in = C.addressof(src)
+    s.avail_in = nxt
+    have -= nxt
+    rcs, out = [], bytearray()
+    while True:
+        s.avail_out = length
+        s.next_out = C.addressof(obuf)
+        rc = l.inflate(C.byref(s), Z_NO_FLUSH)
+        rcs.append(rc)
+        out += obuf.raw[:length - s.avail_out]
+        if rc not in (Z_OK, Z_BUF_ERROR):
+            break
+        have += s.avail_in
+        nxt = sizes.pop(0) if sizes else step
+        s.avail_in = min(nxt, have)
+        have -= s.avail_in
+        if s.avail_in == 0:
+            break
+        if len(rcs) > 10000:
+            break
+    msg = s.msg.decode() if s.msg else None
+    l.inflateEnd(C.byref(s))
+    return rcs, bytes(out), msg

@@ -2,6 +2,7 @@
 include/*.h declares; calls that need a device fail loudly instead of falling
 back to a CPU path.  CPU only (no compute calls)."""
 import ctypes
+import subprocess
 import os
 import re
 
@@ -110,3 +111,23 @@ def test_zlib_api_host_logic_without_compute():
     assert lib.compressBound(1 << 20) >= (1 << 20) + (1 << 8) + (1 << 6) + 13
     tab = lib.get_crc_table()
     assert tab[1] == 0x77073096 and tab[255] == 0x2d02ef8d
+
+
+def test_symbol_versions_and_soname():
+    """libzamd_z.so carries the reference's symbol versions (zlib.map:1-83), so that programs linked against a versioned
+    libz find e.g. deflatePending@ZLIB_1.2.5.1 when it is preloaded.  Its SONAME is its own: as libz.so.1 it would also be
+    handed to libelf inside the ROCm runtime, whose inflate() calls during HSA start-up would re-enter this library."""
+    so = os.path.join(ROOT, "zlib_amd", "libzamd_z.so")
+    dyn = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "Library soname: [libzamd_z.so]" in dyn
+    ver = subprocess.run(["readelf", "-V", so], capture_output=True, text=True).stdout
+    for node in ("ZLIB_1.2.0", "ZLIB_1.2.2.3", "ZLIB_1.2.5.1", "ZLIB_1.2.7.1"):
+        assert node in ver, node
+    syms = subprocess.run(["nm", "-D", so], capture_output=True, text=True).stdout
+    assert "deflatePending@@ZLIB_1.2.5.1" in syms and "inflateGetDictionary@@ZLIB_1.2.7.1" in syms
+    assert " T _Z" not in syms                       # no C++ internals exported
+    exe = os.path.join(ROOT, "examples", "zamd_gzip")
+    if os.path.exists(exe):
+        ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+        line = [ln for ln in ldd.splitlines() if "libzamd_z.so" in ln]
+        assert line and os.path.realpath(line[0].split("=>")[1].split("(")[0].strip()) == os.path.realpath(so), ldd

@@ -209,3 +209,33 @@ def test_the_example_program_on_a_64_mib_file(tmp_path):
     os.remove(name)
     subprocess.run([exe, "-d", name + ".gz"], check=True, timeout=300)
     assert open(name, "rb").read() == data
+
+
+def test_a_failing_engine_call_is_an_error_of_gzwrite(tmp_path):
+    """deflate() of this library can fail where the reference's cannot (device memory, engine errors).  gzwrite must
+    then report the failure (0 bytes written, gzerror Z_MEM_ERROR) and must not come back to the caller's buffer on the
+    next call (gzwrite.c:74-131 only ever sees Z_STREAM_ERROR).  The failure is injected: ZAMD_Z_FAIL_DEFLATE_AFTER.
+    Runs in a process of its own because the switch is counted per process."""
+    script = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(%r, "tests"))
+import _zapi as Z
+l = Z.lib()
+name = sys.argv[1].encode()
+big = bytes(range(256)) * (40 << 10)            # 10 MiB: goes to deflate() from the caller's buffer
+os.environ["ZAMD_Z_FAIL_DEFLATE_AFTER"] = "1"
+g = l.gzopen(name, b"wb6")
+assert l.gzbuffer(g, 1 << 20) == 0
+assert l.gzwrite(g, big, len(big)) == len(big)  # buffered by deflate(): no engine call yet
+assert l.gzflush(g, Z.Z_SYNC_FLUSH) == 0        # engine call 1 goes through
+assert l.gzwrite(g, big, len(big)) == len(big)
+rc = l.gzflush(g, Z.Z_SYNC_FLUSH)               # engine call 2 fails
+err = C.c_int(0)
+msg = l.gzerror(g, C.byref(err))
+assert rc == Z.Z_MEM_ERROR and err.value == Z.Z_MEM_ERROR and msg == b"out of memory", (rc, err.value, msg)
+assert l.gzwrite(g, b"abc", 3) == 0             # the error sticks (gzwrite.c:177-178), and no stale pointer is followed
+assert l.gzclose(g) == Z.Z_MEM_ERROR
+print("ok")
+''' % ROOT
+    r = subprocess.run([os.sys.executable, "-c", script, str(tmp_path / "f.gz")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

@@ -581,3 +581,122 @@ def test_streams_of_different_threads():
     for t in threads:
         t.join()
     assert all(results.get(k) is True for k in range(6)), results
+
+
+@pytest.mark.parametrize("in_step", [None, 3000, 700])
+def test_bytes_behind_a_stream_go_back_to_the_call_that_brought_them(in_step, monkeypatch):
+    """Two gzip members of highly compressible data with a small output batch: decoding stops again and again with
+    output waiting while the end of the first member and the whole second member are already buffered.  After
+    Z_STREAM_END next_in must stand exactly behind the first member's trailer (inflate.c:1198-1208), whatever the
+    feeding pattern, so that the second member is not lost."""
+    import gzip
+    monkeypatch.setenv("ZAMD_Z_OUT_BATCH_MIB", "8")     # a block of zeros from level 6 inflates to 4 MiB: two blocks a round
+    a = bytes(40 << 20)
+    b = O.corpus(300000, 0, 71)
+    m1, m2 = gzip.compress(a, 6), gzip.compress(b, 6)
+    comp = m1 + m2
+    l = Z.lib()
+    s = Z.ZStream()
+    assert l.inflateInit2_(C.byref(s), 31, Z.VERSION, Z.SZ) == 0
+    src = C.create_string_buffer(comp, len(comp))
+    obuf = C.create_string_buffer(1 << 20)
+    outs, cur = [], bytearray()
+    pos, n = 0, len(comp)
+    step = in_step or n
+    guard = 0
+    while len(outs) < 2:
+        guard += 1
+        assert guard < 100000
+        avail = min(step, n - pos)
+        s.next_in, s.avail_in = C.addressof(src) + pos, avail
+        s.next_out, s.avail_out = C.addressof(obuf), 1 << 20
+        rc = l.inflate(C.byref(s), Z.Z_NO_FLUSH)
+        assert rc in (Z.Z_OK, Z.Z_STREAM_END, Z.Z_BUF_ERROR), (rc, s.msg)
+        used = avail - s.avail_in
+        assert 0 <= used <= avail and s.next_in == C.addressof(src) + pos + used
+        pos += used
+        cur += obuf.raw[:(1 << 20) - s.avail_out]
+        if rc == Z.Z_STREAM_END:
+            outs.append(bytes(cur)); cur = bytearray()
+            if len(outs) == 1:
+                assert pos == len(m1), (pos, len(m1))
+                assert s.total_in == len(m1)
+                assert l.inflateReset(C.byref(s)) == 0
+    assert outs[0] == a and outs[1] == b and pos == n
+    assert l.inflateEnd(C.byref(s)) == 0
+
+
+INF_VEC = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inflate_vectors.json")))["inf"]
+
+
+@pytest.mark.parametrize("v", INF_VEC, ids=lambda v: v["what"].replace(" ", "_"))
+def test_inf_harness_vectors_of_the_reference_test(v):
+    """The vectors of the reference's inf() harness (test/infcover.c:367-371, 611-613, 643-658) through the harness's own
+    loop: the first inflate() call gives the stated code; a stream that ends gives the reference's bytes, a broken one
+    the reference's message (both taken from the reference build where it is present)."""
+    rcs, out, msg = Z.inf_loop(Z.lib(), v["hex"], v["step"], v["win"], v["len"])
+    assert rcs[0] == v["err"], (rcs, msg)
+    ref = Z.ref_lib()
+    if ref is not None:
+        rrcs, rout, rmsg = Z.inf_loop(ref, v["hex"], v["step"], v["win"], v["len"])
+        assert rrcs[0] == v["err"]
+        if rrcs[-1] == Z.Z_STREAM_END:
+            assert rcs[-1] == Z.Z_STREAM_END and out == rout
+        if rrcs[-1] == Z.Z_DATA_ERROR:
+            assert rcs[-1] == Z.Z_DATA_ERROR and msg == rmsg
+
+
+def _bits_lsb(fields):
+    """(value, nbits, is_huffman_code) -> bytes, LSB first; Huffman codes go in most significant bit first."""
+    acc, n = 0, 0
+    for val, nb, code in fields:
+        if code:
+            val = int(("{:0%db}" % nb).format(val)[::-1], 2)
+        acc |= val << n
+        n += nb
+    return acc.to_bytes((n + 7) // 8, "little")
+
+
+@pytest.mark.parametrize("win,ok", [(-8, False), (-9, True), (-15, True)])
+def test_a_distance_beyond_the_declared_window_is_too_far_back(win, ok):
+    """A stored block of 300 bytes in one inflate() call, then, in the next call, a match at distance 300: with a
+    256-byte window (windowBits 8) the bytes are gone (inflate.c:379-427, 1122-1134), with 512 bytes or more they are
+    there.  The expectation comes from the reference build where it is present."""
+    body = O.corpus(300, 1, 99)
+    b1 = bytes([0]) + (300).to_bytes(2, "little") + (300 ^ 0xffff).to_bytes(2, "little") + body
+    # final fixed block: length 3 (code 257, 7 bits), distance 300 (code 16, 5 bits, 7 extra bits = 300 - 257), end of block
+    b2 = _bits_lsb([(1, 1, False), (1, 2, False), (1, 7, True), (16, 5, True), (43, 7, False), (0, 7, True)])
+    stream = b1 + b2
+    rcs, out, msg = Z.inf_loop(Z.lib(), stream, 0, win, 400, pieces=[len(b1), len(b2)])
+    ref = Z.ref_lib()
+    if ref is not None:
+        rrcs, rout, rmsg = Z.inf_loop(ref, stream, 0, win, 400, pieces=[len(b1), len(b2)])
+        assert (rrcs[-1] == Z.Z_STREAM_END) == ok and (ok or rmsg == "invalid distance too far back")
+    if ok:
+        assert rcs[-1] == Z.Z_STREAM_END and out == body + body[:3]
+    else:
+        assert rcs[-1] == Z.Z_DATA_ERROR and msg == "invalid distance too far back" and out == body
+
+
+def test_get_crc_table_hands_out_all_eight_tables():
+    """crc32.c:190-199 returns crc_table[8][256] (crc32.c:90-125); callers that slice by four read tables 1-3."""
+    l = Z.lib()
+    t = l.get_crc_table()
+    tab = [[t[k * 256 + n] for n in range(256)] for k in range(8)]
+    for n in (0, 1, 2, 127, 128, 255):
+        for k in range(4):
+            want = zlib.crc32(bytes([n]) + bytes(k), 0xffffffff) ^ 0xffffffff      # raw register: byte n then k zero bytes
+            assert tab[k][n] == want, (k, n)
+            assert tab[k + 4][n] == int.from_bytes(want.to_bytes(4, "little"), "big")
+    # a slice-by-four CRC over the tables equals crc32()
+    data = O.corpus(1001, 4, 5)
+    c = 0xffffffff
+    i = 0
+    while i + 4 <= len(data):
+        c ^= int.from_bytes(data[i:i + 4], "little")
+        c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24]
+        i += 4
+    for b in data[i:]:
+        c = tab[0][(c ^ b) & 0xff] ^ (c >> 8)
+    assert c ^ 0xffffffff == zlib.crc32(data) == l.crc32(0, data, len(data))
+    assert l.zamd_z_last_error() == 0

@@ -199,3 +199,17 @@ def test_boundary_rows(r):
                                       flush=_ZFLUSH[r["flush"]], want_state=True)
     assert len(out) == r["out_len"] and "%08x" % zlib.crc32(out) == r["out_crc"]
     assert (pb, pv, dt) == (r["pend_bits"], r["pend_val"], r["data_type"])
+
+
+def test_transcribed_inf_vectors_give_the_stated_codes_on_the_reference_build():
+    """tests/golden/inflate_vectors.json "inf" was transcribed from test/infcover.c; where the reference build exists it
+    must give the stated return code on the first inflate() call, run through the harness's own loop."""
+    import _zapi as Z
+    l = Z.ref_lib()
+    if l is None:
+        pytest.skip("reference build absent")
+    vec = json.load(open(os.path.join(ROOT, "tests", "golden", "inflate_vectors.json")))["inf"]
+    assert len(vec) == 15
+    for v in vec:
+        rcs, out, msg = Z.inf_loop(l, v["hex"], v["step"], v["win"], v["len"])
+        assert rcs[0] == v["err"], v["what"]

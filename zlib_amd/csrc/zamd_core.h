@@ -657,32 +657,34 @@ ZC_HD uint32_t zc_parse_huff(uint32_t dict_len, uint32_t len, uint32_t final_, c
 template <int N>
 struct ZcTree {
     enum { HEAP = 2 * N + 1 };
+    uint32_t pq[HEAP + 1];         /* the priority queue of build_tree: freq << 16 | depth << 10 | node (see zc_build_tree) */
     uint16_t freq[HEAP];
     uint16_t dad[HEAP];
-    uint16_t heap[HEAP];
+    uint16_t heap[HEAP];           /* the nodes in the order they left the queue (trees.c:664, 682), read by gen_bitlen */
     uint8_t  len[HEAP + 3];
-    uint8_t  depth[HEAP + 3];
     uint16_t bl_count[16];
     int32_t  max_code;
+    uint32_t deep;                 /* set when a subtree grew deeper than the packed key can hold (it cannot: see below) */
 };
 
-template <int N>
-ZC_HD bool zc_smaller(const ZcTree<N> &t, uint32_t n, uint32_t m)   /* trees.c:443 */
-{
-    uint32_t fn = t.freq[n], fm = t.freq[m];
-    return fn < fm || (fn == fm && t.depth[n] <= t.depth[m]);
-}
+/* The queue holds one word per node: frequency (16 bits: a block has at most lit_bufsize symbols), depth of the subtree
+ * (6 bits: a subtree of depth d weighs at least Fibonacci(d), so depth stays below 24 for frequencies that add up to
+ * less than 65536) and node number (10 bits).  smaller(n, m) of trees.c:443-445 — frequency, then depth, "<=" on
+ * ties — is then one comparison of the words without their node bits, and pqdownheap never touches freq[] or
+ * depth[]: the serial dependent loads per level drop from six to one. */
+#define ZC_PQ_KEY(e) ((e) >> 10)
 template <int N>
 ZC_HD void zc_sift(ZcTree<N> &t, int heap_len, int k)               /* pqdownheap, trees.c:453 */
 {
-    uint32_t v = t.heap[k];
+    const uint32_t v = t.pq[k];
     int j = k << 1;
     while (j <= heap_len) {
-        if (j < heap_len && zc_smaller(t, t.heap[j + 1], t.heap[j])) j++;
-        if (zc_smaller(t, v, t.heap[j])) break;
-        t.heap[k] = t.heap[j]; k = j; j <<= 1;
+        uint32_t a = t.pq[j];
+        if (j < heap_len) { const uint32_t b = t.pq[j + 1]; if (ZC_PQ_KEY(b) <= ZC_PQ_KEY(a)) { j++; a = b; } }
+        if (ZC_PQ_KEY(v) <= ZC_PQ_KEY(a)) break;
+        t.pq[k] = a; k = j; j <<= 1;
     }
-    t.heap[k] = (uint16_t)v;
+    t.pq[k] = v;
 }
 
 /* stlen(n) = static code length of symbol n (or 0 when the tree has no static
@@ -693,31 +695,37 @@ ZC_HD void zc_build_tree(ZcTree<N> &t, int max_length, bool has_static, StLen st
 {
     const int HEAP = ZcTree<N>::HEAP;
     int heap_len = 0, heap_max = HEAP, max_code = -1, n, m, node;
+    t.deep = 0;
     for (n = 0; n < N; n++) {
-        if (t.freq[n] != 0) { t.heap[++heap_len] = (uint16_t)(max_code = n); t.depth[n] = 0; }
+        if (t.freq[n] != 0) { t.pq[++heap_len] = ((uint32_t)t.freq[n] << 16) | (uint32_t)(max_code = n); }
         else t.len[n] = 0;
     }
     while (heap_len < 2) {                                           /* trees.c:648-654 */
         node = (max_code < 2 ? ++max_code : 0);
-        t.heap[++heap_len] = (uint16_t)node;
-        t.freq[node] = 1; t.depth[node] = 0;
+        t.pq[++heap_len] = (1u << 16) | (uint32_t)node;
+        t.freq[node] = 1;
         (*opt_len)--; if (has_static) *static_len -= stlen(node);
     }
     t.max_code = max_code;
     for (n = heap_len / 2; n >= 1; n--) zc_sift(t, heap_len, n);
     node = N;
     do {
-        n = t.heap[1]; t.heap[1] = t.heap[heap_len--]; zc_sift(t, heap_len, 1);
-        m = t.heap[1];
+        const uint32_t en = t.pq[1];
+        t.pq[1] = t.pq[heap_len--]; zc_sift(t, heap_len, 1);
+        const uint32_t em = t.pq[1];
+        n = (int)(en & 1023u); m = (int)(em & 1023u);
         t.heap[--heap_max] = (uint16_t)n; t.heap[--heap_max] = (uint16_t)m;
-        t.freq[node] = (uint16_t)(t.freq[n] + t.freq[m]);
-        uint32_t dn = t.depth[n], dm = t.depth[m];
-        t.depth[node] = (uint8_t)((dn >= dm ? dn : dm) + 1);
+        const uint32_t f = (en >> 16) + (em >> 16);
+        const uint32_t dn = (en >> 10) & 63u, dm = (em >> 10) & 63u;
+        uint32_t d = (dn >= dm ? dn : dm) + 1u;
+        if (d > 63u) { d = 63u; t.deep = 1; }
+        t.freq[node] = (uint16_t)f;
         t.dad[n] = t.dad[m] = (uint16_t)node;
-        t.heap[1] = (uint16_t)node++;
+        t.pq[1] = (f << 16) | (d << 10) | (uint32_t)node;
+        node++;
         zc_sift(t, heap_len, 1);
     } while (heap_len >= 2);
-    t.heap[--heap_max] = t.heap[1];
+    t.heap[--heap_max] = (uint16_t)(t.pq[1] & 1023u);
 
     /* gen_bitlen */
     int h, bits, overflow = 0;

@@ -44,7 +44,7 @@
 #define ZK_EMIT_THREADS  256
 #define ZK_STAGE_WORDS   400                  /* 31 + 256*48 + 31 bits */
 
-enum { ZE_CHAIN_ORDER = 1, ZE_BLOCK_OVERFLOW = 2, ZE_OUT_OVERFLOW = 4, ZE_INFLATE_DATA = 8 };
+enum { ZE_CHAIN_ORDER = 1, ZE_BLOCK_OVERFLOW = 2, ZE_OUT_OVERFLOW = 4, ZE_INFLATE_DATA = 8, ZE_TREE_DEPTH = 16 };
 
 struct ZkJob {
     const uint8_t *in; uint64_t n;
@@ -68,21 +68,34 @@ struct ZkJob {
 
 /* ------------------------------------------------------------------ k_chain
  * INSERT_STRING (deflate.c:186-189) for every position of one chunk (plus its
- * 32 KiB dictionary), head table in LDS.  The strings are inserted in position
+ * dictionary), head table in LDS.  The strings must be inserted in position
  * order per hash value, which is all the chains need: the 16 wavefronts of the
  * workgroup split the HASH VALUES between them (hash mod 16), so each wave owns
- * its slice of the head table and walks the chunk in order, 1024 positions per
- * round: hashes are computed once per round by all waves together, then every
- * wave picks its own strings out of the round.  The LDS atomic max returns the
- * previous (older) position with that hash — lanes and successive steps hold
- * increasing positions — which becomes the chain link. */
+ * its slice of the head table.  Per round of 1024 positions: every thread hashes
+ * one position and files it under the wavefront that owns its hash (a counting
+ * sort by owner that keeps position order: rank inside the filing wavefront from
+ * a returning LDS add, offsets from the 16 x 16 table of counts, which every
+ * wavefront sums for itself), then every
+ * wavefront inserts the positions filed under it, 64 to an instruction, all lanes
+ * busy.  The LDS atomic max returns the previous (older) position with that hash —
+ * lanes and successive steps hold increasing positions — which becomes the chain
+ * link.  (LDS serves the lanes of one atomic instruction that hit one address in
+ * lane order; a violation would show as a chain that runs forwards and raises
+ * ZE_CHAIN_ORDER.) */
 #define ZK_CHAIN_THREADS 1024
 #define ZK_CHAIN_ROUND   1024u
+/* A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store of the
+ * wave (s_waitcnt vmcnt(0)): with a prefetch in flight that exposes a trip to memory at every barrier.  The data handed
+ * between waves here lives in LDS; global loads are consumed by the thread that issued them (the compiler waits for
+ * those itself), global stores are read by later kernels only. */
+#define ZK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
 {
     __shared__ uint32_t head[32768];
-    __shared__ uint16_t s_hash[2][ZK_CHAIN_ROUND];
-    __shared__ uint16_t s_link[2][ZK_CHAIN_ROUND];
+    __shared__ uint16_t s_hash[ZK_CHAIN_ROUND];       /* hash of every position of the round, 0xffff = not part of this pass */
+    __shared__ uint16_t s_link[ZK_CHAIN_ROUND];
+    __shared__ uint16_t s_sorted[ZK_CHAIN_ROUND];     /* filed positions ordered by (owner, position); bit 15: opens a run */
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[16][16];   /* [owner][wavefront]: how many positions the wavefront files under the owner */
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t c = J.chunk0 + blockIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head, J.P.wsize);
@@ -112,40 +125,70 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     };
     for (uint32_t pass = 0; pass < passes; pass++) {
         for (uint32_t i = tid; i < 32768; i += ZK_CHAIN_THREADS) head[i] = 0;
-        uint32_t w0, w1, buf = 0;
+        if (tid < 256) (&s_cnt[0][0])[tid] = 0;
+        uint32_t w0, w1;
         fetch(tid, w0, w1);
         __syncthreads();
-        for (uint32_t r0 = 0; r0 < Ex; r0 += ZK_CHAIN_ROUND, buf ^= 1u) {
-            /* hashes of this round, one position per thread; 0xffff = not part of this pass */
+        for (uint32_t r0 = 0; r0 < Ex; r0 += ZK_CHAIN_ROUND) {
+            /* 1. the hash of this thread's position.  A stretch of equal hashes inside one wavefront (a run of one byte
+             *    value, mostly) needs the table twice only: the string that opens it reads the previous occurrence, the
+             *    one that closes it leaves its position behind; every string in between links to its neighbour, one back.
+             *    Only opening and closing strings are filed; `rank` numbers them among those their wavefront files under
+             *    the same owner. */
+            const uint32_t a = r0 + tid;
+            uint32_t hv = 0xffffu, rank = 0;
+            if (a < Ex) {
+                uint32_t b3 = __builtin_amdgcn_alignbyte(w1, w0, (a + mis) & 3u);
+                uint32_t h = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
+                if ((h >> 15) == pass) hv = h & 32767u;
+            }
+            const uint32_t hp = __shfl_up(hv, 1), hn = __shfl_down(hv, 1);
+            const bool opens = lane == 0 || hp != hv, closes = lane == 63 || hn != hv;
+            const bool filed = hv != 0xffffu && (opens || closes);
+            s_hash[tid] = (uint16_t)hv;
+            s_link[tid] = 1;
+            /* the owner mixes all hash bits: the low four alone are the low nibble of the string's third byte */
+            const uint32_t own = (hv ^ (hv >> 5) ^ (hv >> 10)) & 15u;
+            if (filed) rank = atomicAdd(&s_cnt[own][wv], 1u);
+            fetch(a + ZK_CHAIN_ROUND, w0, w1);
+            ZK_LDS_BARRIER();
+            /* 2. counts -> offsets, by every wavefront for itself (lane d of every group of 16 takes owner d): where owner
+             *    d's stretch of s_sorted starts, and where inside it the positions of this wavefront go */
+            uint32_t seg0, seg1;
             {
-                uint32_t a = r0 + tid, hv = 0xffffu;
-                if (a < Ex) {
-                    uint32_t b3 = __builtin_amdgcn_alignbyte(w1, w0, (a + mis) & 3u);
-                    uint32_t h = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
-                    if ((h >> 15) == pass) hv = h & 32767u;
+                const uint32_t d = lane & 15u;
+                uint32_t run = 0, before = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 16; q += 4) {
+                    const uint4 n4 = *(const uint4 *)&s_cnt[d][q];
+                    const uint32_t n[4] = {n4.x, n4.y, n4.z, n4.w};
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) { if (q + k == wv) before = run; run += n[k]; }
                 }
-                s_hash[buf][tid] = (uint16_t)hv;
-                fetch(a + ZK_CHAIN_ROUND, w0, w1);
+                uint32_t incl = run;                                  /* scan of the owners' totals over each group of 16 lanes */
+                for (uint32_t k = 1; k < 16; k <<= 1) { const uint32_t y = __shfl_up(incl, k, 16); if (d >= k) incl += y; }
+                const uint32_t start = incl - run;
+                /* 3. file the position: lane `own` of this lane's group of 16 holds that owner's numbers */
+                const uint32_t base = __shfl(start + before, own, 16);
+                if (filed) s_sorted[base + rank] = (uint16_t)(tid | (opens ? 0x8000u : 0u));
+                seg0 = __shfl(start, wv, 16);
+                seg1 = __shfl(incl, wv, 16);
             }
-            __syncthreads();
-            /* each wave inserts the strings whose hash it owns, in position order */
-#pragma unroll 4
-            for (uint32_t q = 0; q < ZK_CHAIN_ROUND; q += 64) {
-                uint32_t hv = s_hash[buf][q + lane];
-                if (hv != 0xffffu && (hv & 15u) == wv) {
-                    uint32_t a = r0 + q + lane;
-                    uint32_t old = atomicMax(&head[hv], a + 1);
-                    if (old > a) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
-                    uint32_t d = old ? a + 1 - old : 0;
-                    s_link[buf][q + lane] = (uint16_t)(d > 32767u ? 0u : d);
+            ZK_LDS_BARRIER();
+            /* 4. every wavefront enters the strings whose hash it owns, in position order */
+            for (uint32_t j = seg0 + lane; j < seg1; j += 64u) {
+                const uint32_t e = s_sorted[j], q = e & 1023u, hq = s_hash[q], aq = r0 + q;
+                uint32_t old = atomicMax(&head[hq], aq + 1);
+                if (old > aq) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
+                if (e & 0x8000u) {
+                    uint32_t d = old ? aq + 1 - old : 0;
+                    s_link[q] = (uint16_t)(d > 32767u ? 0u : d);
                 }
             }
-            __syncthreads();
-            {
-                uint32_t a = r0 + tid;
-                if (a < Ex && a >= out_from && s_hash[buf][tid] != 0xffffu) pd[a] = s_link[buf][tid];
-            }
-            /* the other buffer pair is written next; this one is reused two rounds on, behind two barriers */
+            if (tid < 256) (&s_cnt[0][0])[tid] = 0;        /* read for the last time in step 2 */
+            ZK_LDS_BARRIER();
+            if (a < Ex && a >= out_from && hv != 0xffffu) pd[a] = s_link[tid];
+            /* s_link[tid] and s_hash[tid] are written again by this thread, and read by others a barrier later */
         }
         __syncthreads();
     }
@@ -357,7 +400,9 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
             for (int u = 0; u < ZK_MATCH_STEPS; u++) {
                 if (wm >= 0) continue;                            /* stopped lanes are masked off, their LDS reads with them */
                 const uint32_t wi = c >> 2;
-                const uint32_t v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], c);   /* the instruction uses bits 1:0 of the shift operand */
+                const uint32_t v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], c);   /* the instruction uses bits 1:0 of the shift operand; one
+                                                                                               * ds_read_b32 at the byte address itself is legal on gfx950 and
+                                                                                               * measured 2.2 times slower for the whole kernel */
                 const int32_t d = (int32_t)link[c];
                 const uint32_t x = (v & 0x00ffffffu) ^ scan3;
                 const int32_t nohit = -(int32_t)x;               /* negative unless the peek matched */
@@ -538,6 +583,10 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
     if (lane == 0) { J.nhop[lc] = H; if (nfall) atomicAdd(J.err + 1, nfall); }
 }
 
+/* The same walk for the hop words of k_resolve, eight chunks to a wavefront.  The walk is serial per chunk and a lone
+ * wavefront per chunk spends its 64 lanes on one chain of dependent LDS reads, so that what bounds the kernel is the
+ * instruction issue of 32 such wavefronts per CU: here a group of eight lanes owns a chunk (its lanes carry identical
+ * values and stage the chunk's hop words through a tile of their own), and one instruction stream advances eight walks. */
 #define ZK_EXPAND_THREADS 256
 __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
 {
@@ -688,6 +737,7 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
         ZcBlockTab *tab = J.tab + (uint64_t)lc * J.P.max_blocks + j;
         zc_plan_block(lt, dt, bt, cost[0] + cost[2], cost[1] + cost[3], J.P.strategy, &b, tab);
         bp->type = b.type; bp->bits = b.bits; bp->hdr_bits = b.hdr_bits;
+        if (lt.deep | dt.deep | bt.deep) atomicOr(J.err, (uint32_t)ZE_TREE_DEPTH);
     }
 }
 
@@ -1310,7 +1360,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (P.parser == ZC_PARSE_SLOW && !dense) {
             tm_begin(e, s, 1, &slot);
             HIPCHK(hipMemsetAsync(w.hop, 0, (uint64_t)J.nchunks * chunk_size * 4u, s));
-            hipLaunchKernelGGL((k_spec<32>), dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles);
+            hipLaunchKernelGGL((k_spec<32>), dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles, ZK_SPEC_SEG);
             tm_end(e, s, slot);
         }
         if (dense) {

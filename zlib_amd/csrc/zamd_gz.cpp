@@ -341,7 +341,14 @@ int comp(GzFile *s, int flush)                          /* gz_comp, gzwrite.c:74
         }
         made = z.avail_out;
         ret = deflate(&z, flush);
-        if (ret == Z_STREAM_ERROR) { set_error(s, Z_STREAM_ERROR, "internal error: deflate stream corrupt"); return -1; }
+        /* unlike the reference's, this deflate() can run out of (device) memory or fail in the engine: anything but
+         * progress, the end of the stream, or "nothing to do" (Z_BUF_ERROR with the input used up) loses data */
+        if (!(ret == Z_OK || ret == Z_STREAM_END || (ret == Z_BUF_ERROR && z.avail_in == 0))) {
+            z.avail_in = 0;                             /* the caller's bytes are not ours to come back to */
+            if (ret == Z_MEM_ERROR) set_error(s, Z_MEM_ERROR, "out of memory");
+            else set_error(s, ret == Z_BUF_ERROR ? Z_BUF_ERROR : Z_STREAM_ERROR, "internal error: deflate stream corrupt");
+            return -1;
+        }
         made -= z.avail_out;
         s->produced += made;
     } while (made);

@@ -41,9 +41,15 @@
 #define ZK_SPEC_LDS   (ZK_SPEC_WIN + 2u * ZK_SPEC_PD)
 
 enum { ZS_ACQ = 0, ZS_RES = 2, ZS_DONE = 3 };
+#ifdef ZAMD_SPEC_STATS
+__device__ unsigned long long g_spec_stats[8];
+#define ZS_STAT(i, v) (st_##i += (v))
+#else
+#define ZS_STAT(i, v) ((void)0)
+#endif
 
 template <int THRESH>
-__global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t tiles_per_chunk)
+__global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t tiles_per_chunk, uint32_t SEGV)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_lds[ZK_SPEC_LDS / 4];
     __shared__ uint32_t s_known[ZK_SPEC_SPAN / 32 + 1];
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
     const uint32_t t0 = g.dict_len + tile * ZK_TILE;
     const uint32_t tlen = (E - t0) < ZK_TILE ? (E - t0) : ZK_TILE;
     const uint32_t limit_end = (E - t0) < tlen + ZK_SPEC_OVER ? E : t0 + tlen + ZK_SPEC_OVER;
-    const uint32_t nseg = (tlen + ZK_SPEC_SEG - 1u) / ZK_SPEC_SEG;
+    const uint32_t nseg = (tlen + SEGV - 1u) / SEGV;
     const int64_t a0 = (int64_t)t0 - (int64_t)ZK_HALO;      /* a-coordinate of LDS byte 0 */
     for (uint32_t v = tid; v < ZK_SPEC_WIN / 16; v += blockDim.x) {
         int64_t a = a0 + 16 * (int64_t)v;
@@ -114,10 +120,15 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
     int32_t kk = 0;                           /* candidates examined minus the budget: negative while budget remains */
     int32_t walking = 0, parked = 0;          /* sign masks: -1 / 0 */
 
+#ifdef ZAMD_SPEC_STATS
+    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_6 = 0, st_7 = 0;
+    const long long t_begin = clock64();
+#endif
     auto start_walk = [&](uint32_t q, uint32_t pl) -> bool {
         ZcMatchState ms;
         if (!zc_match_init(win, pd, q, E, g.corner, nice_match, ms, max_dist)) return false;
         if (pl >= ms.cap) return false;
+        ZS_STAT(2, 1);
         p = q; cur = ms.cur; cap = ms.cap; nice = ms.nice; best = pl; plen = pl; bdist = 0;
         scan3 = pl > 2u ? (win.load4(q + pl - 2u) & 0x00ffffffu) : ms.scan3;
         kk = -(int32_t)(pl >= good ? qbudget : max_chain);
@@ -128,6 +139,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
     for (;;) {
         /* ---- full comparisons of parked candidates */
         if (parked < 0) {
+            ZS_STAT(6, 1);
             uint32_t len = 0;
             while (len < cap) {
                 uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
         for (int pass = 0; pass < 2; pass++) {
             const bool sv = walking == 0 && st != ZS_DONE;
             if (__ballot(sv) == 0ull) break;
+            if ((tid & 63u) == 0) ZS_STAT(4, 1);
             /* 1. the search's result (deflate.c:1771-1815) */
             const bool res = sv && st == ZS_RES;
             const bool acc = res && best > plen && !(best <= 5u && (filt || (best == ZC_MIN_MATCH && bdist > ZC_TOO_FAR)));
@@ -162,6 +175,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
             const bool hop_done = res && !probe;
             /* 2. a complete hop is recorded */
             if (hop_done) hop[hp - g.dict_len] = L ? zc_hop_pack(k, L, D) : 1u;
+            if (hop_done) ZS_STAT(3, 1);
             const uint32_t cnd = L ? hp + k + L : hp + 1u;
             /* 3. where the parse goes on: behind the hop unless somebody has been there or it is out of reach,
              *    else at the next speculative starting point */
@@ -176,11 +190,11 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
                 st = ZS_ACQ;
                 if (seg >= nseg) st = ZS_DONE;
                 else {
-                    const uint32_t i = seg * ZK_SPEC_SEG;
+                    const uint32_t i = seg * SEGV;
                     if (!((atomicOr(&s_known[i >> 5], 1u << (i & 31u)) >> (i & 31u)) & 1u)) { have = true; nhp = t0 + i; }
                     /* a parse that has not met another one ZK_SPEC_OVER positions past its own stretch gives up:
                      * where matches are that long, searches are cheap and k_hop does the few it needs itself */
-                    reach = t0 + i + ZK_SPEC_SEG + ZK_SPEC_OVER;
+                    reach = t0 + i + SEGV + ZK_SPEC_OVER;
                     if (reach > limit_end) reach = limit_end;
                 }
             }
@@ -203,10 +217,14 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
         uint32_t c = cur;                     /* candidate */
         const int32_t plim = (int32_t)p - lim;       /* the next candidate c' is in reach while plim - c' < 0 */
         int32_t wm = walking;
+#ifdef ZAMD_SPEC_STATS
+        const long long t_w = clock64();
+#endif
 #pragma unroll 1
         for (int it = 0; it < 32; it++) {
 #pragma unroll
             for (int u = 0; u < 2; u++) {
+                ZS_STAT(0, wm < 0 ? 1 : 0); ZS_STAT(1, 1);
                 const uint32_t ac = c + peek_off;
                 const uint32_t wi = ac >> 2;
                 const uint32_t v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], ac & 3u);
@@ -222,11 +240,27 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_spec(ZkJob J, uint32_t til
             }
             if ((uint32_t)__popcll(__ballot(wm == 0 && st != ZS_DONE)) >= thr) break;
         }
+#ifdef ZAMD_SPEC_STATS
+        if ((tid & 63u) == 0) st_5 += (unsigned long long)(clock64() - t_w);
+#endif
         cur = c;
         parked >>= 31;
         walking = wm | parked;                /* parked walks are still owned by the lane */
     }
+#ifdef ZAMD_SPEC_STATS
+    if ((tid & 63u) == 0) st_7 = (unsigned long long)(clock64() - t_begin);
+    atomicAdd(&g_spec_stats[0], st_0); atomicAdd(&g_spec_stats[1], st_1); atomicAdd(&g_spec_stats[2], st_2); atomicAdd(&g_spec_stats[3], st_3);
+    atomicAdd(&g_spec_stats[4], st_4); atomicAdd(&g_spec_stats[5], st_5); atomicAdd(&g_spec_stats[6], st_6); atomicAdd(&g_spec_stats[7], st_7);
+#endif
 }
+#ifdef ZAMD_SPEC_STATS
+extern "C" int zamd_debug_spec_stats(unsigned long long *out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_spec_stats), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_spec_stats), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 /* Accessors of k_hop's own searches: window bytes and links straight from global memory. */
 struct GlbWin {

@@ -206,6 +206,12 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     std::lock_guard<std::mutex> lk(g_gpu.mu);
     zamd_engine *e = engine_locked();
     if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
+    // fault injection for tests of the callers' error paths (the allocator fake of test/infcover.c:55-234 plays this
+    // part for the reference): ZAMD_Z_FAIL_DEFLATE_AFTER=k lets k engine calls through, then reports out of memory
+    if (const char *fv = getenv("ZAMD_Z_FAIL_DEFLATE_AFTER")) {
+        static long calls = 0;
+        if (calls++ >= atol(fv)) return Z_MEM_ERROR;
+    }
     const uint32_t wsize = 1u << s->w_bits;
     uint32_t head = s->hist_len;
     uint64_t bound = zamd_deflate_bound(n, s->chunk_size, s->mem_level);
@@ -616,7 +622,23 @@ struct IState {
     uint64_t out_batch;
     uint64_t prime_hold; unsigned prime_bits;   // inflatePrime bits waiting in front of the first input byte
     std::vector<uint32_t> hints; size_t hint_pos;   // chunk index of the deflate data ahead (zamd_inflate_index_hint): compressed bytes, inflated bytes per chunk
+    size_t call_taken;              // bytes the current inflate() call has moved from next_in to the end of `in`
 };
+
+// Hands the bytes at the end of `in` that the current call took (at most `want` of them) back to the caller.
+// Bytes of earlier calls cannot go back: the caller's next_in no longer points behind them.
+size_t unread_tail(z_streamp strm, IState *s, size_t want) {
+    size_t mine = s->call_taken < s->in.size() ? s->call_taken : s->in.size();
+    size_t k = want < mine ? want : mine;
+    if (k == 0) return 0;
+    strm->next_in -= k; strm->avail_in += (uInt)k; strm->total_in -= k;
+    s->in.resize(s->in.size() - k);
+    s->call_taken -= k;
+    while (!s->cands.empty() && s->cands.back() > s->in.size()) s->cands.pop_back();
+    if (s->scanned > s->in.size()) s->scanned = s->in.size();
+    s->tried = 0;
+    return k;
+}
 
 inline IState *istate(z_streamp strm) {
     if (strm == Z_NULL || strm->state == Z_NULL) return nullptr;
@@ -964,10 +986,13 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         }
         tr.lap("download");
         s->total += produced;
-        if (produced >= HIST) s->hist.assign(got + produced - HIST, got + produced);
+        // the window carried from round to round holds 1 << windowBits bytes (updatewindow, inflate.c:379-427): a
+        // distance that reaches further back than that into an earlier round is "too far back" (inflate.c:1122-1134)
+        const size_t wlim = s->wbits >= 8 && s->wbits < 15 ? (size_t)1 << s->wbits : HIST;
+        if (produced >= wlim) s->hist.assign(got + produced - wlim, got + produced);
         else {
             s->hist.insert(s->hist.end(), got, got + produced);
-            if (s->hist.size() > HIST) s->hist.erase(s->hist.begin(), s->hist.end() - HIST);
+            if (s->hist.size() > wlim) s->hist.erase(s->hist.begin(), s->hist.end() - wlim);
         }
     }
     // drop the consumed input
@@ -1070,6 +1095,7 @@ int inflate(z_streamp strm, int flush) {
     if (s->mode == IM_MEM) return Z_MEM_ERROR;
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
     int ret = Z_OK;
+    s->call_taken = 0;
     for (;;) {
         idrain(strm, s);
         if (s->mode == IM_TRAILER) {
@@ -1077,7 +1103,7 @@ int inflate(z_streamp strm, int flush) {
             // behind the stream can be handed back to that call's next_in.
             size_t need = s->wrap ? (s->gzip ? 8 : 4) : 0;
             while (s->in.size() < need && strm->avail_in != 0) {
-                s->in.push_back(*strm->next_in++); strm->avail_in--; strm->total_in++;
+                s->in.push_back(*strm->next_in++); strm->avail_in--; strm->total_in++; s->call_taken++;
             }
             if (need && s->in.size() >= 4) {               // the check value is compared as soon as it is there (inflate.c:1176-1192)
                 const uint8_t *t = s->in.data();
@@ -1091,8 +1117,9 @@ int inflate(z_streamp strm, int flush) {
                 uint32_t isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
                 if (isize != (uint32_t)(s->total & 0xffffffffu)) ibad(strm, s, "incorrect length check");
             }
-            size_t extra = s->in.size() - need;
-            strm->next_in -= extra; strm->avail_in += (uInt)extra; strm->total_in -= extra;
+            // what follows the stream goes back to the caller: every such byte came in with this call, because a call
+            // that returns with output pending hands its unused input back (below)
+            unread_tail(strm, s, s->in.size() - need);
             s->in.clear(); s->cands.clear(); s->scanned = 0;
             if (s->mode != IM_BAD) s->mode = IM_DONE;
             continue;
@@ -1136,7 +1163,7 @@ int inflate(z_streamp strm, int flush) {
             uint64_t take = strm->avail_in < room ? strm->avail_in : room;
             if (take) {
                 s->in.insert(s->in.end(), strm->next_in, strm->next_in + take);
-                strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take;
+                strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take; s->call_taken += take;
             }
             if (tried_all) s->tried = s->in.size();
             if (s->in.size() == s->tried) break;             // nothing new since the last fruitless attempt
@@ -1146,6 +1173,10 @@ int inflate(z_streamp strm, int flush) {
         }
         break;
     }
+    // A round can stop before the buffered input is used up (output batch, segment count): the call then returns with
+    // output waiting, and whatever it took and did not decode goes back to the caller.  The end of the stream may be
+    // in there, with bytes of whatever follows it, and those can only be returned by the call that took them.
+    if (s->out.size() != s->out_pos && s->mode == IM_BODY) unread_tail(strm, s, s->in.size());
     strm->data_type = (int)s->bit_off + (s->last ? 64 : 0) + (s->mode == IM_BODY ? 128 : 0);
     if (((in0 == strm->avail_in && out0 == strm->avail_out) || flush == Z_FINISH) && ret == Z_OK) ret = Z_BUF_ERROR;
     return ret;
@@ -1160,7 +1191,8 @@ int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
         if (id != s->check) return Z_DATA_ERROR;
     }
     s->hist.insert(s->hist.end(), dictionary, dictionary + dictLength);
-    if (s->hist.size() > HIST) s->hist.erase(s->hist.begin(), s->hist.end() - HIST);
+    const size_t wlim = s->wbits >= 8 && s->wbits < 15 ? (size_t)1 << s->wbits : HIST;
+    if (s->hist.size() > wlim) s->hist.erase(s->hist.begin(), s->hist.end() - wlim);
     s->havedict = true;
     return Z_OK;
 }
@@ -1319,18 +1351,32 @@ int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen)
 }
 
 // ------------------------------------------------------------------ checksums
+// adler32() and crc32() cannot report an error through their return value (zlib.h:1569-1617), and this library can
+// fail where the reference cannot (no GPU, no device memory).  A failure is therefore made loud: a line on stderr,
+// a sticky error code (zamd_z_last_error), and the caller's running value comes back unchanged.
+static int g_sticky_error = 0;
+static uLong checksum_failed(int crc, uLong start, int code, const char *what) {
+    g_sticky_error = code;
+    fprintf(stderr, "zamd_z: %s() failed (%s, code %d): the returned value is the running value it was given, not a checksum\n",
+            crc ? "crc32" : "adler32", what, code);
+    return start;
+}
 static uLong checksum_host_buf(int crc, uLong start, const Bytef *buf, uInt len) {
     if (buf == Z_NULL) return crc ? 0UL : 1UL;
     if (len == 0) return start;
     std::lock_guard<std::mutex> lk(g_gpu.mu);
     zamd_engine *e = engine_locked();
-    if (!e) return crc ? 0UL : 1UL;                       // no GPU: no result (the initial value)
-    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, (uint64_t)len + 64) != Z_OK) return crc ? 0UL : 1UL;
+    if (!e) return checksum_failed(crc, start, g_gpu.rc ? g_gpu.rc : Z_STREAM_ERROR, "no GPU engine");
+    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, (uint64_t)len + 64) != Z_OK) return checksum_failed(crc, start, Z_MEM_ERROR, "device memory");
     uint32_t v = (uint32_t)start;
-    if (zamd_dev_upload(e, g_gpu.d_in, buf, len) != 0) return crc ? 0UL : 1UL;
-    int rc = crc ? zamd_crc32_dev(e, v, g_gpu.d_in, len, &v) : zamd_adler32_dev(e, v, g_gpu.d_in, len, &v);
-    return rc == 0 ? (uLong)v : (crc ? 0UL : 1UL);
+    int rc = zamd_dev_upload(e, g_gpu.d_in, buf, len);
+    if (rc != 0) return checksum_failed(crc, start, rc, "upload");
+    rc = crc ? zamd_crc32_dev(e, v, g_gpu.d_in, len, &v) : zamd_adler32_dev(e, v, g_gpu.d_in, len, &v);
+    return rc == 0 ? (uLong)v : checksum_failed(crc, start, rc, "kernel");
 }
+
+// 0, or the code of the last failure of a call that has no way to report one (adler32, crc32); reading clears it.
+int zamd_z_last_error(void) { int e = g_sticky_error; g_sticky_error = 0; return e; }
 
 uLong adler32(uLong adler, const Bytef *buf, uInt len) { return checksum_host_buf(0, adler, buf, len); }
 uLong crc32(uLong crc, const Bytef *buf, uInt len) { return checksum_host_buf(1, crc, buf, len); }
@@ -1339,17 +1385,29 @@ uLong adler32_combine64(uLong a1, uLong a2, z_off64_t len2) { return zamd_adler3
 uLong crc32_combine(uLong c1, uLong c2, z_off_t len2) { return zamd_crc32_combine((uint32_t)c1, (uint32_t)c2, len2); }
 uLong crc32_combine64(uLong c1, uLong c2, z_off64_t len2) { return zamd_crc32_combine((uint32_t)c1, (uint32_t)c2, len2); }
 
-const z_crc_t *get_crc_table(void) {      // crc32.c:190-199: the byte-wise table (first of the reference's eight)
-    static z_crc_t table[256];
+const z_crc_t *get_crc_table(void) {
+    // crc32.c:190-199 hands out all of crc_table[8][256] (crc32.c:90-125): table k < 4 holds the CRC of byte n followed
+    // by k zero bytes, tables 4-7 the same values byte-swapped (the word-at-a-time tables of big-endian machines).
+    // Callers that slice by four read all of them.
+    static z_crc_t table[8][256];
     static std::once_flag once;
     std::call_once(once, [] {
+        auto swap = [](uint32_t x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); };
         for (uint32_t n = 0; n < 256; n++) {
             uint32_t c = n;
             for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xedb88320u & (0u - (c & 1)));
-            table[n] = c;
+            table[0][n] = c;
+        }
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = table[0][n];
+            table[4][n] = swap(c);
+            for (int k = 1; k < 4; k++) {
+                c = table[0][c & 0xffu] ^ (c >> 8);            // one more zero byte behind it
+                table[k][n] = c; table[k + 4][n] = swap(c);
+            }
         }
     });
-    return table;
+    return &table[0][0];
 }
 
 // ------------------------------------------------------------------ inflateBack (infback.c:28-640)
