@@ -182,6 +182,8 @@ int zamd_inflate_shard_finish_dev(zamd_engine *e, const void *d_head_window);
  * the batches are cut the same way but all issued to one stream, so that every kernel runs alone on the GPU, which
  * is what per-kernel timing needs (zamd_last_timing_ms then returns durations that add up, not overlapping spans). */
 int zamd_engine_set_streams(zamd_engine *e, int nstreams, int serialize);
+/* The number of streams deflate calls are spread over at present (0: no engine). */
+int zamd_engine_streams(zamd_engine *e);
 
 /*
  * General form: inflate a list of segments of one raw deflate stream, one GPU
@@ -248,12 +250,24 @@ int64_t zamd_debug_dump(zamd_engine *e, int what, uint32_t chunk, void *host_buf
  * generated by `threads` host threads. */
 void zamd_corpus_fill_pieces(uint8_t *buf, uint64_t n, int kind, uint64_t seed, uint64_t piece_bytes, int threads);
 
+/* `fn(arg)` is called from inside every following deflate call of this engine, on the calling thread, when the call's last
+ * kernel has been queued and before the call starts to wait for the GPU (NULL: no call).  A copy between pageable host
+ * memory and the device holds a lock of the GPU runtime for its whole length, and kernel launches of other threads
+ * wait for it: a caller that overlaps the transfers of one batch with the kernels of another starts the transfers
+ * from here.  No counterpart in the reference. */
+int zamd_engine_on_launched(zamd_engine *e, void (*fn)(void *), void *arg);
+
 /* Thin device-memory helpers so that a C or ctypes caller needs no HIP headers
  * (hipMalloc / hipFree / hipMemcpy on the engine's device). */
 int zamd_dev_alloc(zamd_engine *e, uint64_t bytes, void **d_ptr);
 int zamd_dev_free(zamd_engine *e, void *d_ptr);
 int zamd_dev_upload(zamd_engine *e, void *d_dst, const void *h_src, uint64_t bytes);
 int zamd_dev_download(zamd_engine *e, void *h_dst, const void *d_src, uint64_t bytes);
+/* The same two transfers through pinned staging buffers of the engine (2 x 32 MiB per direction, allocated at first
+ * use): for transfers that run beside the kernels of a deflate call, where the runtime's own path for pageable memory
+ * slows down several times.  One staged upload and one staged download may run at a time, from different threads. */
+int zamd_dev_upload_staged(zamd_engine *e, void *d_dst, const void *h_src, uint64_t bytes);
+int zamd_dev_download_staged(zamd_engine *e, void *h_dst, const void *d_src, uint64_t bytes);
 int zamd_dev_memset(zamd_engine *e, void *d_dst, int value, uint64_t bytes);
 
 const char *zamd_version(void);

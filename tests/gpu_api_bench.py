@@ -1,9 +1,11 @@
-"""Manual tool: host-buffer (PCIe-inclusive) rate of the stream API.  usage: gpu_api_bench.py [MiB] [level]"""
+"""Manual tool: host-buffer (PCIe-inclusive) rate of the stream API.  usage: gpu_api_bench.py [MiB] [level] [pinned]"""
 import ctypes as C
 import sys
 import time
 
-sys.path.insert(0, "tests")
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import _zapi as Z
 import zlib_amd
 
@@ -16,6 +18,15 @@ l = Z.lib()
 cap = l.compressBound(n)
 out = C.create_string_buffer(cap)
 back = C.create_string_buffer(n)
+if len(sys.argv) > 3 and sys.argv[3] == "pinned":      # the caller's buffers registered with the GPU beforehand
+    tiny = C.create_string_buffer(1 << 16); tl = C.c_ulong(1 << 16)
+    l.compress.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_void_p, C.c_ulong]
+    assert l.compress(tiny, C.byref(tl), src, 1000) == 0        # brings the GPU runtime up
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+    for buf, sz in ((src, n), (out, cap), (back, n)):
+        rc = hip.hipHostRegister(C.addressof(buf), sz, 0)
+        print("hipHostRegister", sz, "->", rc, flush=True)
 for it in range(2):
     s = Z.ZStream()
     assert l.deflateInit2_(C.byref(s), level, 8, 31, 8, 0, Z.VERSION, Z.SZ) == 0

@@ -12,6 +12,7 @@ import pytest
 
 import _oracle as O
 import _zapi as Z
+import zlib_amd
 
 pytestmark = pytest.mark.gpu
 
@@ -700,3 +701,26 @@ def test_get_crc_table_hands_out_all_eight_tables():
         c = tab[0][(c ^ b) & 0xff] ^ (c >> 8)
     assert c ^ 0xffffffff == zlib.crc32(data) == l.crc32(0, data, len(data))
     assert l.zamd_z_last_error() == 0
+
+
+@pytest.mark.parametrize("wbits,first_flush", [(31, None), (15, Z.Z_SYNC_FLUSH), (-15, Z.Z_FULL_FLUSH), (15, Z.Z_PARTIAL_FLUSH), (-15, Z.Z_BLOCK)])
+def test_overlapped_batches_equal_batches_in_a_row(monkeypatch, wbits, first_flush):
+    """deflate() with several whole batches of input and room for their output overlaps upload, kernels and download of
+    consecutive batches (the flush's own batch included).  The stream must be the one the same call produces batch by
+    batch, and the one a caller with a small output buffer gets."""
+    import zlib as pyz
+    monkeypatch.setenv("ZAMD_Z_BATCH_MIB", "1")
+    monkeypatch.setenv("ZAMD_Z_CHUNK", "262144")
+    data = bytes(zlib_amd.corpus((5 << 20) + 300001, 4, 11))
+    cut = (4 << 20) + 77
+    flushes = {cut: first_flush} if first_flush is not None else None
+    big = len(data) + (len(data) >> 3) + (1 << 16)
+    idx_a, idx_b = [], []
+    piped, tot_p = Z.deflate_stream(data, 6, wbits, out_step=big, flushes=flushes, index=idx_a)
+    monkeypatch.setenv("ZAMD_Z_NO_PIPELINE", "1")
+    plain, tot_q = Z.deflate_stream(data, 6, wbits, out_step=big, flushes=flushes, index=idx_b)
+    monkeypatch.delenv("ZAMD_Z_NO_PIPELINE")
+    small, tot_s = Z.deflate_stream(data, 6, wbits, out_step=70000, flushes=flushes)
+    assert piped == plain and tot_p == tot_q and idx_a == idx_b
+    assert small == plain and tot_s == tot_q
+    assert pyz.decompressobj(wbits).decompress(piped) == data

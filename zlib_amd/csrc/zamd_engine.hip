@@ -24,6 +24,7 @@
  * Inflate: zamd_inflate_impl.h.
  */
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1058,6 +1059,15 @@ struct zamd_engine {
     int device;
     ZiState *inf;                 /* batch-inflate workspace, created on first use */
     hipStream_t st[ZE_STREAMS];
+    void (*on_launched)(void *); void *on_launched_arg;   /* called once per deflate call when its last kernel is queued */
+    uint8_t *h_stage[2][2];         /* pinned staging for zamd_dev_upload_staged / _download_staged: [direction][half], ZE_STAGE_BYTES each */
+    uint32_t *h_res;                /* 64 bytes of pinned host memory: where a call's totals and flags arrive */
+    hipStream_t st_up, st_down;     /* host copies run on a stream of their own (a plain hipMemcpy takes the null stream), so that one thread's
+                                     * transfers and the kernels of another thread's deflate call overlap.  A process has GPU_MAX_HW_QUEUES
+                                     * (4) hardware queues and streams beyond that share them: a copy queued behind this engine's kernels in
+                                     * a shared queue was measured at a quarter of its speed.  Hence one stream for both directions, and a
+                                     * caller that overlaps transfers with a deflate call runs that call on three streams
+                                     * (zamd_engine_set_streams). */
     hipEvent_t ev_scan[ZE_STREAMS], ev_init;
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
@@ -1133,6 +1143,8 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     for (int i = 0; i < ZE_STREAMS; i++) e->ws[i] = ZeWorkspace();
     e->nstreams = 4;                 /* one per hardware queue (GPU_MAX_HW_QUEUES defaults to 4) */
     e->wbits = 15; e->data_type = 2;
+    e->on_launched = nullptr; e->on_launched_arg = nullptr;
+    for (int d = 0; d < 2; d++) for (int h = 0; h < 2; h++) e->h_stage[d][h] = nullptr;
     e->spec_match = getenv("ZAMD_MATCH_SPEC") ? 1 : 0;
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->serialize = getenv("ZAMD_SERIALIZE") ? 1 : 0;
@@ -1142,6 +1154,9 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
         HIPCHK(hipStreamCreateWithFlags(&e->st[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&e->ev_scan[i], hipEventDisableTiming));
     }
+    HIPCHK(hipHostMalloc((void **)&e->h_res, 64, hipHostMallocDefault));
+    HIPCHK(hipStreamCreateWithFlags(&e->st_up, hipStreamNonBlocking));
+    e->st_down = e->st_up;         /* one stream for both directions: see ZE_STREAMS_BESIDE_COPIES */
     HIPCHK(hipEventCreateWithFlags(&e->ev_init, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&e->ev_call[i]));
     HIPCHK(hipMalloc((void **)&e->d_total, 8));
@@ -1169,6 +1184,9 @@ extern "C" void zamd_engine_destroy(zamd_engine *e)
     zi_free(e);
     for (int i = 0; i < ZE_STREAMS; i++) { ws_free(e->ws[i]); hipStreamDestroy(e->st[i]); hipEventDestroy(e->ev_scan[i]); }
     for (int i = 0; i < 2; i++) hipEventDestroy(e->ev_call[i]);
+    hipStreamDestroy(e->st_up);
+    hipHostFree(e->h_res);
+    for (int d = 0; d < 2; d++) for (int h = 0; h < 2; h++) if (e->h_stage[d][h]) hipHostFree(e->h_stage[d][h]);
     hipEventDestroy(e->ev_init);
     for (int i = 0; i < e->cap_tm; i++) { hipEventDestroy(e->tm[i].a); hipEventDestroy(e->tm[i].b); }
     free(e->tm);
@@ -1200,6 +1218,8 @@ extern "C" int zamd_engine_set_streams(zamd_engine *e, int nstreams, int seriali
     e->nstreams = nstreams; e->serialize = serialize ? 1 : 0;
     return ZAMD_OK;
 }
+
+extern "C" int zamd_engine_streams(zamd_engine *e) { return e ? e->nstreams : 0; }
 
 extern "C" int zamd_engine_window_bits(zamd_engine *e, int window_bits)
 {
@@ -1301,6 +1321,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     out_cap &= ~15ull;
     const uint32_t prime_bits = e->prime_bits, prime_val = e->prime_val;
     e->prime_bits = 0; e->prime_val = 0;
+    const auto host_t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(e->device));
     const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
     /* batch size from the workspace budget, two batches in flight */
@@ -1405,25 +1426,33 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (bi == 0) { e->last_job = J; e->have_last = true; }
     }
     HIPCHK(hipGetLastError());
+    const auto host_t1 = std::chrono::steady_clock::now();
+    if (e->on_launched) e->on_launched(e->on_launched_arg);
     for (int i = 1; i < NS && (uint32_t)i < nbatches; i++) HIPCHK(hipStreamSynchronize(e->st[i]));
     HIPCHK(hipEventRecord(e->ev_call[1], s0));
+    /* the call's results come back through pinned memory on the call's own stream: a blocking hipMemcpy would queue
+     * behind whatever large host copy another thread has in flight */
+    HIPCHK(hipMemcpyAsync(e->h_res, e->d_total, 8, hipMemcpyDeviceToHost, s0));
+    HIPCHK(hipMemcpyAsync(e->h_res + 2, e->d_err, 16, hipMemcpyDeviceToHost, s0));
     HIPCHK(hipStreamSynchronize(s0));
-    uint64_t total = 0; uint32_t err = 0;
-    HIPCHK(hipMemcpy(&total, e->d_total, 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&err, e->d_err, 4, hipMemcpyDeviceToHost));
-    uint32_t ev[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpy(ev, e->d_err, 16, hipMemcpyDeviceToHost));
+    uint64_t total = 0; uint32_t ev[4] = {0, 0, 0, 0};
+    memcpy(&total, e->h_res, 8); memcpy(ev, e->h_res + 2, 16);
+    const uint32_t err = ev[0];
     e->last_fallback_hops = ev[1];
     e->data_type = ev[2] ? (int)ev[2] - 1 : 2;
     if (!finish && P.tail != ZC_TAIL_SYNC && ev[3] && !(err & ~0u)) {
         /* the bits behind the last complete byte wait for the next call, as they would in bi_buf */
-        uint8_t last = 0;
-        HIPCHK(hipMemcpy(&last, (const uint8_t *)d_out + total, 1, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpyAsync(e->h_res + 8, (const uint8_t *)d_out + total, 1, hipMemcpyDeviceToHost, s0));
+        HIPCHK(hipStreamSynchronize(s0));
+        const uint8_t last = (uint8_t)(e->h_res[8] & 0xffu);
         e->pend_bits = ev[3]; e->pend_val = last & ((1u << ev[3]) - 1u);
     }
     for (int k = 0; k < 12; k++) { e->t_ms[k] = 0; e->t_n[k] = 0; }
     for (int i = 0; i < e->n_tm; i++) { float ms = 0; if (hipEventElapsedTime(&ms, e->tm[i].a, e->tm[i].b) == hipSuccess) { e->t_ms[e->tm[i].which] += ms; e->t_n[e->tm[i].which]++; } }
     { float ms = 0; if (hipEventElapsedTime(&ms, e->ev_call[0], e->ev_call[1]) == hipSuccess) { e->t_ms[6] = ms; e->t_n[6] = 1; } }
+    /* the host's side of the call: until the last kernel was queued, and from there to the results */
+    e->t_ms[7] = std::chrono::duration<double, std::milli>(host_t1 - host_t0).count(); e->t_n[7] = 1;
+    e->t_ms[8] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t1).count(); e->t_n[8] = 1;
     if (total_out) *total_out = total;
     if (err & ZE_OUT_OVERFLOW) return ZAMD_BUF_ERROR;
     if (err) { fprintf(stderr, "zamd: device reported internal error flags 0x%x\n", err); return ZAMD_STREAM_ERROR; }
@@ -1557,6 +1586,12 @@ extern "C" int zamd_crc32_dev(zamd_engine *e, uint32_t crc, const void *d_in, ui
 #include "zamd_fast_impl.h"
 
 /* ------------------------------------------------------------------ device-memory helpers */
+extern "C" int zamd_engine_on_launched(zamd_engine *e, void (*fn)(void *), void *arg)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    e->on_launched = fn; e->on_launched_arg = arg;
+    return ZAMD_OK;
+}
 extern "C" int zamd_dev_alloc(zamd_engine *e, uint64_t bytes, void **d_ptr)
 {
     if (!e || !d_ptr) return ZAMD_STREAM_ERROR;
@@ -1572,12 +1607,74 @@ extern "C" int zamd_dev_free(zamd_engine *e, void *d_ptr)
 extern "C" int zamd_dev_upload(zamd_engine *e, void *d_dst, const void *h_src, uint64_t bytes)
 {
     if (!e) return ZAMD_STREAM_ERROR;
-    HIPCHK(hipSetDevice(e->device)); if (bytes) HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice)); return ZAMD_OK;
+    HIPCHK(hipSetDevice(e->device));
+    if (bytes) { HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->st_up)); HIPCHK(hipStreamSynchronize(e->st_up)); }
+    return ZAMD_OK;
 }
 extern "C" int zamd_dev_download(zamd_engine *e, void *h_dst, const void *d_src, uint64_t bytes)
 {
     if (!e) return ZAMD_STREAM_ERROR;
-    HIPCHK(hipSetDevice(e->device)); if (bytes) HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost)); return ZAMD_OK;
+    HIPCHK(hipSetDevice(e->device));
+    if (bytes) { HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, e->st_down)); HIPCHK(hipStreamSynchronize(e->st_down)); }
+    return ZAMD_OK;
+}
+/* The same transfers through pinned staging memory of the engine, the host's own memcpy on one side and the copy
+ * engine on the other, two pieces in flight.  Beside running kernels the runtime's path for pageable memory was
+ * measured four to five times slower than alone; this one keeps its pace.  One upload and one download may run at the
+ * same time (from two threads), not two of a kind; both directions share one stream, in the order they were queued. */
+#define ZE_STAGE_BYTES (32ull << 20)
+static int stage_ready(zamd_engine *e, int dir)
+{
+    for (int h = 0; h < 2; h++)
+        if (!e->h_stage[dir][h]) HIPCHK(hipHostMalloc((void **)&e->h_stage[dir][h], ZE_STAGE_BYTES, hipHostMallocDefault));
+    return ZAMD_OK;
+}
+extern "C" int zamd_dev_upload_staged(zamd_engine *e, void *d_dst, const void *h_src, uint64_t bytes)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    if (int rc = stage_ready(e, 0)) return rc;
+    hipEvent_t ev[2];
+    for (int h = 0; h < 2; h++) HIPCHK(hipEventCreateWithFlags(&ev[h], hipEventDisableTiming));
+    int rc = ZAMD_OK;
+    uint64_t piece = 0;
+    for (uint64_t at = 0; at < bytes && rc == ZAMD_OK; at += ZE_STAGE_BYTES, piece++) {
+        const int h = (int)(piece & 1);
+        const uint64_t len = bytes - at < ZE_STAGE_BYTES ? bytes - at : ZE_STAGE_BYTES;
+        if (piece >= 2 && hipEventSynchronize(ev[h]) != hipSuccess) { rc = ZAMD_HIP_ERROR(1); break; }   /* the half is free again */
+        memcpy(e->h_stage[0][h], (const uint8_t *)h_src + at, len);
+        if (hipMemcpyAsync((uint8_t *)d_dst + at, e->h_stage[0][h], len, hipMemcpyHostToDevice, e->st_up) != hipSuccess ||
+            hipEventRecord(ev[h], e->st_up) != hipSuccess) rc = ZAMD_HIP_ERROR(1);
+    }
+    if (hipStreamSynchronize(e->st_up) != hipSuccess) rc = ZAMD_HIP_ERROR(1);
+    for (int h = 0; h < 2; h++) hipEventDestroy(ev[h]);
+    return rc;
+}
+extern "C" int zamd_dev_download_staged(zamd_engine *e, void *h_dst, const void *d_src, uint64_t bytes)
+{
+    if (!e) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    if (int rc = stage_ready(e, 1)) return rc;
+    hipEvent_t ev[2];
+    for (int h = 0; h < 2; h++) HIPCHK(hipEventCreateWithFlags(&ev[h], hipEventDisableTiming));
+    int rc = ZAMD_OK;
+    const uint64_t pieces = (bytes + ZE_STAGE_BYTES - 1) / ZE_STAGE_BYTES;
+    /* piece k + 1 is on its way while the host copies piece k out */
+    for (uint64_t k = 0; k <= pieces && rc == ZAMD_OK; k++) {
+        if (k < pieces) {
+            const uint64_t at = k * ZE_STAGE_BYTES, len = bytes - at < ZE_STAGE_BYTES ? bytes - at : ZE_STAGE_BYTES;
+            if (hipMemcpyAsync(e->h_stage[1][k & 1], (const uint8_t *)d_src + at, len, hipMemcpyDeviceToHost, e->st_down) != hipSuccess ||
+                hipEventRecord(ev[k & 1], e->st_down) != hipSuccess) { rc = ZAMD_HIP_ERROR(1); break; }
+        }
+        if (k >= 1) {
+            const uint64_t at = (k - 1) * ZE_STAGE_BYTES, len = bytes - at < ZE_STAGE_BYTES ? bytes - at : ZE_STAGE_BYTES;
+            if (hipEventSynchronize(ev[(k - 1) & 1]) != hipSuccess) { rc = ZAMD_HIP_ERROR(1); break; }
+            memcpy((uint8_t *)h_dst + at, e->h_stage[1][(k - 1) & 1], len);
+        }
+    }
+    if (hipStreamSynchronize(e->st_down) != hipSuccess) rc = ZAMD_HIP_ERROR(1);
+    for (int h = 0; h < 2; h++) hipEventDestroy(ev[h]);
+    return rc;
 }
 extern "C" int zamd_dev_memset(zamd_engine *e, void *d_dst, int value, uint64_t bytes)
 {

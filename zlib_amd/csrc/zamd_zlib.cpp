@@ -23,6 +23,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <condition_variable>
 #include <new>
 #include <vector>
 
@@ -41,6 +43,8 @@ struct Gpu {
     bool tried = false;
     uint8_t *d_in = nullptr;  uint64_t in_cap = 0;    // staging: [32 KiB history][batch]
     uint8_t *d_out = nullptr; uint64_t out_cap = 0;
+    uint8_t *d_in_b = nullptr; uint64_t in_cap_b = 0;    // the second pair, used while batches of one call overlap
+    uint8_t *d_out_b = nullptr; uint64_t out_cap_b = 0;
     uint64_t *d_off = nullptr; uint64_t off_cap = 0;
 };
 Gpu g_gpu;
@@ -199,87 +203,101 @@ void write_header(z_streamp strm, DState *s) {     // deflate.c:690-867
     s->status = ST_BUSY;
 }
 
-// Compress `n` bytes at `src` (host) as chunks primed with the stream's history;
-// append the result to s->out and fold the bytes into strm->adler.
-// `tail`: how the output ends when finish == 0 (ZAMD_TAIL_*: sync marker, _tr_align, nothing).
-int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int finish, int tail = ZAMD_TAIL_SYNC) {
-    std::lock_guard<std::mutex> lk(g_gpu.mu);
-    zamd_engine *e = engine_locked();
-    if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
+// One batch of input on its way through the GPU: upload, engine call, download.  The three steps are separate so
+// that consecutive batches of one deflate() call can overlap them (run_batches_piped); run_batch does them in a row.
+struct Batch {
+    const uint8_t *src; uint64_t n;          // input of the batch (host)
+    const uint8_t *head_src; uint32_t head;  // the history that primes it: `head` bytes ending at head_src + head
+    int finish, tail, slot;                  // slot: which pair of staging buffers
+    uint64_t bound, total;                   // room reserved for the output, bytes produced
+};
+
+inline uint8_t *&slot_in(int k) { return k ? g_gpu.d_in_b : g_gpu.d_in; }
+inline uint64_t &slot_in_cap(int k) { return k ? g_gpu.in_cap_b : g_gpu.in_cap; }
+inline uint8_t *&slot_out(int k) { return k ? g_gpu.d_out_b : g_gpu.d_out; }
+inline uint64_t &slot_out_cap(int k) { return k ? g_gpu.out_cap_b : g_gpu.out_cap; }
+
+int batch_reserve(zamd_engine *e, DState *s, Batch &b) {
+    b.bound = zamd_deflate_bound(b.n, s->chunk_size, s->mem_level);
+    if (grow(e, &slot_in(b.slot), &slot_in_cap(b.slot), HIST + b.n + 64) != Z_OK) return Z_MEM_ERROR;
+    if (grow(e, &slot_out(b.slot), &slot_out_cap(b.slot), b.bound + 64) != Z_OK) return Z_MEM_ERROR;
+    return Z_OK;
+}
+// `beside`: the transfer runs while another batch is on the GPU
+int batch_upload(zamd_engine *e, const Batch &b, bool beside = false) {
+    uint8_t *d = slot_in(b.slot);
+    int (*const up)(zamd_engine *, void *, const void *, uint64_t) = beside ? zamd_dev_upload_staged : zamd_dev_upload;
+    int rc = 0;
+    if (b.head && b.head_src + b.head == b.src) return up(e, d + (HIST - b.head), b.head_src, (uint64_t)b.head + b.n);   // one piece of host memory
+    if (b.head) rc = zamd_dev_upload(e, d + (HIST - b.head), b.head_src, b.head);
+    if (rc == 0 && b.n) rc = up(e, d + HIST, b.src, b.n);
+    return rc;
+}
+// The engine call of a batch and what it leaves in the stream state: chunk index, pending bits, data type, check value.
+int batch_compute(z_streamp strm, DState *s, zamd_engine *e, Batch &b, Trace &tr) {
     // fault injection for tests of the callers' error paths (the allocator fake of test/infcover.c:55-234 plays this
     // part for the reference): ZAMD_Z_FAIL_DEFLATE_AFTER=k lets k engine calls through, then reports out of memory
     if (const char *fv = getenv("ZAMD_Z_FAIL_DEFLATE_AFTER")) {
         static long calls = 0;
-        if (calls++ >= atol(fv)) return Z_MEM_ERROR;
+        if (calls++ >= atol(fv)) return ZAMD_MEM_ERROR;
     }
-    const uint32_t wsize = 1u << s->w_bits;
-    uint32_t head = s->hist_len;
-    uint64_t bound = zamd_deflate_bound(n, s->chunk_size, s->mem_level);
-    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, HIST + n + 64) != Z_OK) return Z_MEM_ERROR;
-    if (grow(e, &g_gpu.d_out, &g_gpu.out_cap, bound + 64) != Z_OK) return Z_MEM_ERROR;
+    const uint64_t n = b.n;
+    uint8_t *d_in = slot_in(b.slot), *d_out = slot_out(b.slot);
     int rc = 0;
-    Trace tr;
-    if (head) rc = zamd_dev_upload(e, g_gpu.d_in + (HIST - head), s->hist.data() + (s->hist_len - head), head);
-    if (rc == 0 && n) rc = zamd_dev_upload(e, g_gpu.d_in + HIST, src, n);
-    tr.lap("upload");
-    uint64_t total = 0;
+    b.total = 0;
+    if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+    if (rc == 0) rc = zamd_engine_window_bits(e, s->w_bits);
+    if (rc == 0 && s->prime_bits) { rc = zamd_engine_prime(e, (int)s->prime_bits, (int)s->prime_val); s->prime_bits = 0; s->prime_val = 0; }
+    if (rc == 0 && !b.finish && b.tail != ZAMD_TAIL_SYNC) { rc = zamd_engine_tail(e, b.tail); s->index_ok = false; }
+    const uint64_t nch = n ? (n + s->chunk_size - 1) / s->chunk_size : 1;
+    uint64_t *d_tab = nullptr;
+    if (rc == 0 && s->index_on && s->index_ok) {
+        if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, (nch + 1) * 8 > HIST ? (nch + 1) * 8 : HIST) != Z_OK) return ZAMD_MEM_ERROR;
+        d_tab = g_gpu.d_off;
+    }
+    if (rc == 0)
+        rc = zamd_deflate_shard_dev(e, d_in + HIST, n, b.head, s->chunk_size, s->level, s->strategy,
+                                    s->mem_level, b.finish, d_out, b.bound, d_tab, &b.total);
+    if (rc == 0 && d_tab) {
+        // chunks end on byte boundaries (a sync marker or the final block), so byte counts describe them
+        std::vector<uint64_t> off(nch + 1);
+        rc = zamd_dev_download(e, off.data(), d_tab, (nch + 1) * 8);
+        for (uint64_t c = 0; rc == 0 && c < nch; c++) {
+            const uint64_t raw = n ? ((c + 1) * s->chunk_size <= n ? s->chunk_size : n - c * s->chunk_size) : 0;
+            s->index.push_back((uint32_t)(off[c + 1] - off[c]));
+            s->index.push_back((uint32_t)raw);
+        }
+    }
+    if (s->tuned) zamd_engine_tune(e, 0, 0, 0, 0);      // the engine is shared by all streams
+    zamd_engine_window_bits(e, 15);
     if (rc == 0) {
-        if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
-        if (rc == 0) rc = zamd_engine_window_bits(e, s->w_bits);
-        if (rc == 0 && s->prime_bits) { rc = zamd_engine_prime(e, (int)s->prime_bits, (int)s->prime_val); s->prime_bits = 0; s->prime_val = 0; }
-        if (rc == 0 && !finish && tail != ZAMD_TAIL_SYNC) { rc = zamd_engine_tail(e, tail); s->index_ok = false; }
-        const uint64_t nch = n ? (n + s->chunk_size - 1) / s->chunk_size : 1;
-        uint64_t *d_tab = nullptr;
-        if (rc == 0 && s->index_on && s->index_ok) {
-            if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, (nch + 1) * 8 > HIST ? (nch + 1) * 8 : HIST) != Z_OK) return Z_MEM_ERROR;
-            d_tab = g_gpu.d_off;
-        }
-        if (rc == 0)
-            rc = zamd_deflate_shard_dev(e, g_gpu.d_in + HIST, n, head, s->chunk_size, s->level, s->strategy,
-                                        s->mem_level, finish, g_gpu.d_out, bound, d_tab, &total);
-        if (rc == 0 && d_tab) {
-            // chunks end on byte boundaries (a sync marker or the final block), so byte counts describe them
-            std::vector<uint64_t> off(nch + 1);
-            rc = zamd_dev_download(e, off.data(), d_tab, (nch + 1) * 8);
-            for (uint64_t c = 0; rc == 0 && c < nch; c++) {
-                const uint64_t raw = n ? ((c + 1) * s->chunk_size <= n ? s->chunk_size : n - c * s->chunk_size) : 0;
-                s->index.push_back((uint32_t)(off[c + 1] - off[c]));
-                s->index.push_back((uint32_t)raw);
-            }
-        }
-        if (s->tuned) zamd_engine_tune(e, 0, 0, 0, 0);      // the engine is shared by all streams
-        zamd_engine_window_bits(e, 15);
-        if (rc == 0) {
-            // bits behind the last whole byte stay in the bit buffer (bi_flush, trees.c:1169-1181): they lead the next block
-            int pb = 0, pv = 0;
-            zamd_engine_pending_bits(e, &pb, &pv);
-            s->prime_bits = (uint32_t)pb; s->prime_val = (uint32_t)pv;
-            // strm->data_type comes from the first block flushed at level > 0 (trees.c:920-921)
-            if (strm->data_type == Z_UNKNOWN) { int dt = zamd_engine_data_type(e); if (dt != Z_UNKNOWN) strm->data_type = dt; }
-        }
+        // bits behind the last whole byte stay in the bit buffer (bi_flush, trees.c:1169-1181): they lead the next block
+        int pb = 0, pv = 0;
+        zamd_engine_pending_bits(e, &pb, &pv);
+        s->prime_bits = (uint32_t)pb; s->prime_val = (uint32_t)pv;
+        // strm->data_type comes from the first block flushed at level > 0 (trees.c:920-921)
+        if (strm->data_type == Z_UNKNOWN) { int dt = zamd_engine_data_type(e); if (dt != Z_UNKNOWN) strm->data_type = dt; }
     }
     tr.lap("deflate");
+    if (tr.on) {       // the engine's own clock: spans of its kernels by stage, and of the whole call
+        char buf[240]; int nl = 0;
+        snprintf(buf, sizeof buf, " [chain %.1f match %.1f parse %.1f plan %.1f emit %.1f call %.1f; host: queueing %.1f waiting %.1f]", zamd_last_timing_ms(e, 0, &nl),
+                 zamd_last_timing_ms(e, 1, &nl), zamd_last_timing_ms(e, 2, &nl), zamd_last_timing_ms(e, 3, &nl), zamd_last_timing_ms(e, 5, &nl), zamd_last_timing_ms(e, 6, &nl),
+                 zamd_last_timing_ms(e, 7, &nl), zamd_last_timing_ms(e, 8, &nl));
+        tr.line += buf;
+    }
     if (rc == 0 && s->wrap && n) {
         uint32_t v = (uint32_t)strm->adler;
-        rc = s->wrap == 2 ? zamd_crc32_dev(e, v, g_gpu.d_in + HIST, n, &v)
-                          : zamd_adler32_dev(e, v, g_gpu.d_in + HIST, n, &v);
+        rc = s->wrap == 2 ? zamd_crc32_dev(e, v, d_in + HIST, n, &v)
+                          : zamd_adler32_dev(e, v, d_in + HIST, n, &v);
         strm->adler = v;
     }
     tr.lap("check");
-    if (rc == 0 && total) {
-        if (s->out.size() == s->out_pos && strm->avail_out >= total) {
-            // nothing pending and room enough: straight into the caller's buffer
-            rc = zamd_dev_download(e, strm->next_out, g_gpu.d_out, total);
-            if (rc == 0) { strm->next_out += total; strm->avail_out -= (uInt)total; strm->total_out += total; }
-        } else {
-            size_t at = s->out.size();
-            s->out.resize(at + total);
-            rc = zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, total);
-        }
-    }
-    tr.lap("download"); tr.done("deflate batch");
-    if (rc != 0) return rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : (rc == ZAMD_BUF_ERROR ? Z_BUF_ERROR : Z_STREAM_ERROR);
-    // history for the next batch = last 32 KiB of everything compressed since the last reset
+    return rc;
+}
+// history for the next batch = the last window of everything compressed since the last reset
+void batch_history(DState *s, const uint8_t *src, uint64_t n) {
+    const uint32_t wsize = 1u << s->w_bits;
     s->since_reset += n;
     if (n >= wsize) {
         s->hist.assign(src + n - wsize, src + n);
@@ -289,14 +307,141 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
         if (s->hist.size() > wsize) s->hist.erase(s->hist.begin(), s->hist.end() - wsize);
         s->hist_len = (uint32_t)s->hist.size();
     }
+}
+inline int z_code(int rc) { return rc == 0 ? Z_OK : rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : (rc == ZAMD_BUF_ERROR ? Z_BUF_ERROR : Z_STREAM_ERROR); }
+
+// Compress `n` bytes at `src` (host) as chunks primed with the stream's history;
+// append the result to s->out and fold the bytes into strm->adler.
+// `tail`: how the output ends when finish == 0 (ZAMD_TAIL_*: sync marker, _tr_align, nothing).
+int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int finish, int tail = ZAMD_TAIL_SYNC) {
+    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    zamd_engine *e = engine_locked();
+    if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
+    Batch b;
+    b.src = src; b.n = n; b.head = s->hist_len; b.head_src = s->hist.data(); b.finish = finish; b.tail = tail; b.slot = 0; b.total = 0;
+    if (batch_reserve(e, s, b) != Z_OK) return Z_MEM_ERROR;
+    Trace tr;
+    int rc = batch_upload(e, b);
+    tr.lap("upload");
+    if (rc == 0) rc = batch_compute(strm, s, e, b, tr);
+    if (rc == 0 && b.total) {
+        if (s->out.size() == s->out_pos && strm->avail_out >= b.total) {
+            // nothing pending and room enough: straight into the caller's buffer
+            rc = zamd_dev_download(e, strm->next_out, g_gpu.d_out, b.total);
+            if (rc == 0) { strm->next_out += b.total; strm->avail_out -= (uInt)b.total; strm->total_out += b.total; }
+        } else {
+            size_t at = s->out.size();
+            s->out.resize(at + b.total);
+            rc = zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, b.total);
+        }
+    }
+    tr.lap("download"); tr.done("deflate batch");
+    if (rc != 0) return z_code(rc);
+    batch_history(s, src, n);
     return Z_OK;
+}
+
+// `count` full batches straight from the caller's input to the caller's output, three at a time in flight: while the
+// engine compresses batch i, one thread uploads batch i + 1 into the other pair of staging buffers and another
+// downloads the output of batch i - 1.  The caller has checked that nothing is pending and that the output has room
+// for the bound of every batch.  Consumes the input and advances the stream counters itself.
+// `last_flush` other than Z_NO_FLUSH: the rest of the input (shorter than a batch, possibly empty) follows as the
+// last batch of the row and ends the way finish_batch would end it.
+int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) {
+    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    zamd_engine *e = engine_locked();
+    if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
+    const uint64_t nb = s->batch_bytes;
+    const uint32_t wsize = 1u << s->w_bits;
+    const uint64_t count = full + (last_flush != Z_NO_FLUSH ? 1 : 0);
+    std::vector<Batch> bs(count);
+    for (uint64_t i = 0; i < count; i++) {
+        Batch &b = bs[i];
+        b.src = strm->next_in + i * nb; b.n = nb; b.finish = 0; b.tail = ZAMD_TAIL_SYNC; b.slot = (int)(i & 1); b.total = 0;
+        if (i == full) {
+            b.n = strm->avail_in - full * nb; b.finish = last_flush == Z_FINISH;
+            b.tail = last_flush == Z_PARTIAL_FLUSH ? ZAMD_TAIL_ALIGN : last_flush == Z_BLOCK ? ZAMD_TAIL_NONE : ZAMD_TAIL_SYNC;   // deflate.c:923-945
+        }
+        if (i == 0) { b.head = s->hist_len; b.head_src = s->hist.data(); }
+        else { b.head = wsize; b.head_src = b.src - wsize; }             // a batch is longer than the window
+        if (i < 2 && batch_reserve(e, s, b) != Z_OK) return Z_MEM_ERROR;   // the buffers are sized once, before any thread uses them
+        b.bound = i == full ? zamd_deflate_bound(b.n, s->chunk_size, s->mem_level) : bs[0].bound;   // never above that of a full batch
+    }
+    std::mutex mu; std::condition_variable cv;
+    uint64_t uploaded = 0, launched = 0, computed = 0, downloaded = 0;
+    int err = 0;
+    // transfers start when the engine call they run beside has queued its kernels (see zamd_engine_on_launched)
+    struct Hook { std::mutex *mu; std::condition_variable *cv; uint64_t *launched; } hook = {&mu, &cv, &launched};
+    const int streams_before = zamd_engine_streams(e);
+    if (streams_before > 3) zamd_engine_set_streams(e, 3, 0);        // the fourth hardware queue is the transfers'
+    zamd_engine_on_launched(e, [](void *p) { Hook *h = (Hook *)p; { std::lock_guard<std::mutex> g(*h->mu); ++*h->launched; } h->cv->notify_all(); }, &hook);
+    uint8_t *const dst0 = strm->next_out;
+    uint64_t out_total = 0;
+    Trace tr;
+    std::vector<double> up_ms(count, 0.0), down_ms(count, 0.0);     // for the trace: how long each transfer took beside the kernels
+    std::thread up([&] {
+        for (uint64_t i = 0; i < count; i++) {
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || (computed + 2 > i && launched + 1 > i); }); if (err) return; }   // batch i - 2 is done with the slot, batch i - 1 is on the GPU
+            const auto t0 = std::chrono::steady_clock::now();
+            int rc = batch_upload(e, bs[i], i > 0);
+            up_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            { std::lock_guard<std::mutex> g(mu); if (rc) err = err ? err : rc; uploaded = i + 1; }
+            cv.notify_all();
+            if (rc) return;
+        }
+    });
+    std::thread down([&] {
+        uint64_t at = 0;
+        for (uint64_t i = 0; i < count; i++) {
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || (computed > i && (launched > i + 1 || i + 1 >= count)); }); if (computed <= i) return; }
+            const auto t0 = std::chrono::steady_clock::now();
+            int rc = bs[i].total ? (i + 1 < count ? zamd_dev_download_staged : zamd_dev_download)(e, dst0 + at, slot_out(bs[i].slot), bs[i].total) : 0;
+            down_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            at += bs[i].total;
+            { std::lock_guard<std::mutex> g(mu); if (rc) err = err ? err : rc; downloaded = i + 1; out_total = at; }
+            cv.notify_all();
+            if (rc) return;
+        }
+    });
+    uint64_t done = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || (uploaded > i && downloaded + 2 > i); }); if (err) break; }
+        tr.lap("wait");
+        int rc = batch_compute(strm, s, e, bs[i], tr);
+        { std::lock_guard<std::mutex> g(mu); if (rc) err = err ? err : rc; else computed = i + 1; }
+        cv.notify_all();
+        if (rc) break;
+        done = i + 1;
+    }
+    { std::lock_guard<std::mutex> g(mu); if (done < count && !err) err = ZAMD_STREAM_ERROR; }
+    cv.notify_all();
+    up.join(); down.join();
+    zamd_engine_on_launched(e, nullptr, nullptr);
+    zamd_engine_set_streams(e, streams_before, 0);
+    if (tr.on) for (uint64_t i = 0; i < count; i++) { char b[64]; snprintf(b, sizeof b, " {up %.1f down %.1f}", up_ms[i], down_ms[i]); tr.line += b; }
+    tr.done("deflate batches, pipelined");
+    // what was compressed and downloaded before a failure stays in the stream, as after a failing run_batch in a row of them
+    const uint64_t good = downloaded < done ? downloaded : done;
+    if (good) {
+        uint64_t bytes = 0;
+        for (uint64_t i = 0; i < good; i++) bytes += bs[i].total;
+        strm->next_out += bytes; strm->avail_out -= (uInt)bytes; strm->total_out += bytes;
+        uint64_t taken = 0;
+        for (uint64_t i = 0; i < good; i++) {
+            if (i + 2 >= good) batch_history(s, bs[i].src, bs[i].n); else s->since_reset += bs[i].n;   // the last two decide the history
+            taken += bs[i].n;
+        }
+        strm->next_in += taken; strm->avail_in -= (uInt)taken; strm->total_in += taken;
+    }
+    return err ? z_code(err) : Z_OK;
 }
 
 void reset_history(DState *s) { s->hist.clear(); s->hist_len = 0; s->since_reset = 0; }
 
-int finish_batch(z_streamp strm, DState *s, int flush) {
+// `compressed`: the engine call that ends the flush has run already (as the last of a row of overlapped batches)
+int finish_batch(z_streamp strm, DState *s, int flush, bool compressed = false) {
     const int tail = flush == Z_PARTIAL_FLUSH ? ZAMD_TAIL_ALIGN : flush == Z_BLOCK ? ZAMD_TAIL_NONE : ZAMD_TAIL_SYNC;   // deflate.c:923-945
-    int rc = run_batch(strm, s, s->in.data(), s->in.size(), flush == Z_FINISH, tail);
+    int rc = compressed ? Z_OK : run_batch(strm, s, s->in.data(), s->in.size(), flush == Z_FINISH, tail);
     if (rc != Z_OK) return rc;
     s->in.clear();
     if (flush == Z_FULL_FLUSH) reset_history(s);          // deflate.c:930-937: forget the history
@@ -478,6 +623,9 @@ uLong deflateBound(z_streamp strm, uLong sourceLen) {
     uint32_t chunk = s ? s->chunk_size : (1u << 20);
     // one engine call per batch, each possibly ending in a sync marker, plus flush markers
     uLong body = (uLong)zamd_deflate_bound(sourceLen, chunk, s ? s->mem_level : 8) + 16;
+    // batches that overlap on the GPU are downloaded straight into the caller's buffer at their bounds' spacing: the
+    // constant part of every batch's bound counts once per batch
+    body += (uLong)(sourceLen / (s && s->batch_bytes >= 65536 ? s->batch_bytes : 65536) + 2) * 160;
     uLong wraplen = 6;
     if (s) {
         if (s->wrap == 0) wraplen = 0;
@@ -520,9 +668,22 @@ int deflate(z_streamp strm, int flush) {
 
     // Accept input; compress whenever a full batch is available.  Input is only
     // accepted while the pending output is empty, which bounds host memory.
+    bool flushed = false;                  // the flush's own engine call has run inside a row of overlapped batches
     while (strm->avail_in != 0) {
         int rc;
-        if (s->in.empty() && strm->avail_in >= s->batch_bytes) {
+        // whole batches that can go straight from the caller's input to the caller's output, overlapped on the GPU
+        uint64_t full = s->in.empty() ? strm->avail_in / s->batch_bytes : 0;
+        bool with_last = flush != Z_NO_FLUSH && s->status != ST_FINISH;
+        if (full >= 1) {
+            const uint64_t per = zamd_deflate_bound(s->batch_bytes, s->chunk_size, s->mem_level) + 64;
+            const uint64_t fit = (uint64_t)strm->avail_out / per;
+            if (full + (with_last ? 1 : 0) > fit) { with_last = false; if (full > fit) full = fit; }
+        }
+        if (full + (with_last ? 1 : 0) >= 2 && full >= 1 && s->out.size() == s->out_pos && s->batch_bytes >= 65536 && !getenv("ZAMD_Z_NO_PIPELINE")) {
+            rc = run_batches_piped(strm, s, full, with_last ? flush : Z_NO_FLUSH);
+            if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
+            if (with_last) { flushed = true; break; }
+        } else if (s->in.empty() && strm->avail_in >= s->batch_bytes) {
             rc = run_batch(strm, s, strm->next_in, s->batch_bytes, 0);
             if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
             strm->next_in += s->batch_bytes; strm->avail_in -= (uInt)s->batch_bytes; strm->total_in += s->batch_bytes;
@@ -541,7 +702,7 @@ int deflate(z_streamp strm, int flush) {
     }
 
     if (flush != Z_NO_FLUSH && s->status != ST_FINISH) {
-        int rc = finish_batch(strm, s, flush);
+        int rc = finish_batch(strm, s, flush, flushed);
         if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
         flush_pending(strm, s);
         if (strm->avail_out == 0 && s->out.size() != s->out_pos) { s->last_flush = -1; return Z_OK; }
