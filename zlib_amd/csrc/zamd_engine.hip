@@ -96,7 +96,10 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     __shared__ uint16_t s_hash[ZK_CHAIN_ROUND];       /* hash of every position of the round, 0xffff = not part of this pass */
     __shared__ uint16_t s_link[ZK_CHAIN_ROUND];
     __shared__ uint16_t s_sorted[ZK_CHAIN_ROUND];     /* filed positions ordered by (owner, position); bit 15: opens a run */
-    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[16][16];   /* [owner][wavefront]: how many positions the wavefront files under the owner */
+    /* [owner][wavefront]: how many positions the wavefront files under the owner.  Rows of 20 words: a wavefront's 64 counting
+     * atomics go to one column, and with rows of 16 that column lies in two LDS banks (eight addresses each); rows of 20
+     * spread it over eight banks and keep the rows aligned for 16-byte reads */
+    __shared__ __attribute__((aligned(16))) uint32_t s_cnt[16][20];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint64_t c = J.chunk0 + blockIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head, J.P.wsize);
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     };
     for (uint32_t pass = 0; pass < passes; pass++) {
         for (uint32_t i = tid; i < 32768; i += ZK_CHAIN_THREADS) head[i] = 0;
-        if (tid < 256) (&s_cnt[0][0])[tid] = 0;
+        if (tid < 320) (&s_cnt[0][0])[tid] = 0;
         uint32_t w0, w1;
         fetch(tid, w0, w1);
         __syncthreads();
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
                     s_link[q] = (uint16_t)(d > 32767u ? 0u : d);
                 }
             }
-            if (tid < 256) (&s_cnt[0][0])[tid] = 0;        /* read for the last time in step 2 */
+            if (tid < 320) (&s_cnt[0][0])[tid] = 0;        /* read for the last time in step 2 */
             ZK_LDS_BARRIER();
             if (a < Ex && a >= out_from && hv != 0xffffu) pd[a] = s_link[tid];
             /* s_link[tid] and s_hash[tid] are written again by this thread, and read by others a barrier later */
