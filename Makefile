@@ -2,7 +2,7 @@
 HIPCC ?= hipcc
 ARCH ?= gfx950
 SRCS = zlib_amd/csrc/zamd_engine.hip zlib_amd/csrc/zamd_corpus.cpp
-HDRS = zlib_amd/csrc/zamd_core.h zlib_amd/csrc/zamd_inflate_impl.h zlib_amd/csrc/zamd_fast_impl.h zlib_amd/csrc/zamd_spec_impl.h include/zamd.h
+HDRS = zlib_amd/csrc/zamd_core.h zlib_amd/csrc/zamd_inflate_impl.h zlib_amd/csrc/zamd_fast_impl.h zlib_amd/csrc/zamd_follow_impl.h include/zamd.h
 
 all: zlib_amd/libzamd.so zlib_amd/libzamd_z.so examples/zamd_gzip oracle
 

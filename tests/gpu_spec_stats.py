@@ -1,12 +1,12 @@
-"""Experiment: counters of the parse-following matcher (needs zlib_amd/libzamd_stats.so, built with -DZAMD_SPEC_STATS)."""
+"""Experiment: counters of the parse-following matcher k_follow (needs zlib_amd/libzamd_stats.so: make zlib_amd/libzamd_stats.so)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["ZAMD_MATCH_SPEC"] = "1"
+os.environ["ZAMD_MATCH_FOLLOW"] = "1"
 import zlib_amd
 zlib_amd.LIB_PATH = os.path.join(os.path.dirname(zlib_amd.__file__), "libzamd_stats.so")
 lib = zlib_amd.load_library()
 n = 256 << 20
-names = ["cand_steps", "lane_slots", "searches", "hops", "service_passes(wave)", "walk_cycles(wave)", "full_compares", "total_cycles(wave)"]
+names = ["cand_steps", "lane_slots", "searches", "hops", "service_passes(wave) / spins", "walk_cycles(wave)", "full_compares / waiting lane-rounds", "total_cycles(wave)"]
 for kind in (0, 2, 3, 4):
     data = zlib_amd.corpus(n, kind, 5, threads=8)
     eng = zlib_amd.Engine(0, workspace_bytes=16 << 30)

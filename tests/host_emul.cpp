@@ -120,7 +120,7 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
             /* k_resolve: hop word per position, literal skips to the next match inside a 1024-position tile */
             std::vector<uint32_t> hop(g.len + 1, 0);
             if (g_hops == 2) {
-                /* k_spec: hops are computed only where a parse arrives; parses start at every 16th position and
+                /* k_follow: hops are computed only where a parse arrives; parses start at every 16th position and
                  * run until they meet a position somebody has been to (0 = nobody) */
                 for (uint32_t s0 = 0; s0 < g.len; s0 += 16)
                     for (uint32_t i = s0; i < g.len && hop[i] == 0;) {

@@ -222,16 +222,16 @@ def test_primed_bits_shift_the_first_chunk_only(engine, level, kind, bits):
 
 
 def test_parse_driven_matcher_is_exact_too():
-    """The matcher that follows the parse (k_spec) instead of searching every position: same bytes, also for
+    """The matcher that follows the parse (k_follow) instead of searching every position: same bytes, also for
     deflateTune values only it can express (nice_length below max_lazy, a quarter budget of zero)."""
     import zlib_amd
     data = O.corpus(3 * 65536 + 77, 4, 81) + O.corpus(150000, 0, 82) + bytes(70000) + O.corpus(100000, 3, 83)
     chunk = 131072
-    os.environ["ZAMD_MATCH_SPEC"] = "1"
+    os.environ["ZAMD_MATCH_FOLLOW"] = "1"
     try:
         eng = zlib_amd.Engine(0)
     finally:
-        del os.environ["ZAMD_MATCH_SPEC"]
+        del os.environ["ZAMD_MATCH_FOLLOW"]
     for level, strategy in ((4, 0), (6, 0), (6, 1), (6, 4), (9, 0)):
         out, _ = eng.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk)
         assert out == O.deflate_chunked(data, chunk, level, strategy, 8)[0], (level, strategy)

@@ -8,7 +8,7 @@
  *             LDS, writes the distance to the previous same-hash string
  *   k_match   longest_match for every position ahead of the parse; window bytes
  *             and chain links of a 16 Ki-position tile (+32 KiB halo) staged in LDS
- *             (k_spec, zamd_spec_impl.h: the search that follows the parse, for
+ *             (k_follow, zamd_follow_impl.h: the search that follows the parse, for
  *             deflateTune values the precomputed records cannot express)
  *   k_resolve / k_hop / k_expand
  *             deflate_slow's lazy evaluation over the match records: per-position
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     }
 }
 
-#include "zamd_spec_impl.h"
+#include "zamd_follow_impl.h"
 
 /* ------------------------------------------------------------------ k_parse
  * One wavefront per chunk.  The lazy-evaluation state machine is serial, so all
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t t
 }
 
 #define ZK_HOP_TILE 512u
-/* SPEC: the hop words come from k_spec: 0 = nobody has been at this position, literals are single steps */
+/* SPEC: the hop words come from k_follow: 0 = nobody has been at this position, literals are single steps */
 template <bool SPEC>
 __global__ __launch_bounds__(64) void k_hop(ZkJob J)
 {
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
         uint32_t h = s_tile[i - base];
         const bool fell = SPEC && h == 0;
         if (fell) {
-            /* nobody has been here (k_spec): search as the parser would, from global memory; every lane the same */
+            /* nobody has been here (k_follow): search as the parser would, from global memory; every lane the same */
             h = zc_hop_direct(gwin, gpd, g.dict_len + i, g.dict_len + g.len, g.corner, J.P);
             if (!h) h = 1;
             nfall++;
@@ -1075,7 +1075,7 @@ struct zamd_engine {
     ZeWorkspace ws[ZE_STREAMS];
     int nstreams;
     int serialize;                  /* batches are cut as for nstreams in flight but issued to one stream: every kernel alone on the GPU */
-    int spec_match;                 /* follow the parse (k_spec) instead of searching every position (k_match) */
+    int spec_match;                 /* follow the parse (k_follow) instead of searching every position (k_match) */
     uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
     int wbits;                        /* windowBits of the following deflate calls (9..15) */
     uint32_t tail_mode;               /* ZC_TAIL_* for the next deflate call only */
@@ -1148,7 +1148,7 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     e->wbits = 15; e->data_type = 2;
     e->on_launched = nullptr; e->on_launched_arg = nullptr;
     for (int d = 0; d < 2; d++) for (int h = 0; h < 2; h++) e->h_stage[d][h] = nullptr;
-    e->spec_match = getenv("ZAMD_MATCH_SPEC") ? 1 : 0;
+    e->spec_match = getenv("ZAMD_MATCH_FOLLOW") ? 1 : 0;
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->serialize = getenv("ZAMD_SERIALIZE") ? 1 : 0;
     e->device = device;
@@ -1379,12 +1379,12 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             tm_end(e, s, slot);
         }
         /* k_match's records reproduce neither a nice length below the lazy limit nor a quarter budget of zero
-         * (which wraps in the reference): those searches follow the parse (k_spec) */
+         * (which wraps in the reference): those searches follow the parse (k_follow) */
         const bool dense = P.parser == ZC_PARSE_RLE || (P.parser == ZC_PARSE_SLOW && !(e->spec_match || P.nice < P.lazy || P.chain < 4));
         if (P.parser == ZC_PARSE_SLOW && !dense) {
             tm_begin(e, s, 1, &slot);
             HIPCHK(hipMemsetAsync(w.hop, 0, (uint64_t)J.nchunks * chunk_size * 4u, s));
-            hipLaunchKernelGGL((k_spec<32>), dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles, ZK_SPEC_SEG);
+            hipLaunchKernelGGL(k_follow, dim3(J.nchunks), dim3(ZF_THREADS), 0, s, J);
             tm_end(e, s, slot);
         }
         if (dense) {
