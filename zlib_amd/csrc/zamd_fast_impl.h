@@ -149,6 +149,15 @@ struct ZkFastCtx {
 #define ZF_ROW (65536u + 32768u)
 #endif
 
+struct GSymRow {
+    uint32_t *s; uint32_t lane; uint32_t *row;
+    __device__ void operator()(uint32_t i, uint32_t w) const
+    {
+        if (lane == (i & 63u)) *row = w;
+        if ((i & 63u) == 63u) s[(i & ~63u) + lane] = *row;
+    }
+};
+
 __global__ __launch_bounds__(64) void k_fast(ZkJob J)
 {
     __shared__ __attribute__((aligned(16))) uint16_t s_prev[ZF_NEAR];
@@ -163,10 +172,14 @@ __global__ __launch_bounds__(64) void k_fast(ZkJob J)
     for (uint32_t i = lane; i < ZF_NEAR; i += 64) s_prev[i] = 0;
     __syncthreads();
     cx.start_batches(0);
-    GSym sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size; sym.lane = lane;
+    /* symbols leave in rows of 64: lane i & 63 keeps symbol i until the row is full.  A store per symbol would sit in
+     * front of the parse's next load (loads and stores of a wavefront complete in order) */
+    uint32_t symrow = 0;
+    GSymRow sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size; sym.lane = lane; sym.row = &symrow;
     GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
     uint32_t nsym = 0;
     const uint32_t nb = zc_parse_fast(g.dict_len, g.len, g.final, J.P, cx, sym, blk, &nsym);
+    if (lane < (nsym & 63u)) sym.s[(nsym & ~63u) + lane] = symrow;          /* the last, partial row */
     if (lane == 0) {
         J.nblk[lc] = nb < J.P.max_blocks ? nb : J.P.max_blocks;
         J.nsym[lc] = nsym;
