@@ -250,6 +250,12 @@ int64_t zamd_debug_dump(zamd_engine *e, int what, uint32_t chunk, void *host_buf
  * generated by `threads` host threads. */
 void zamd_corpus_fill_pieces(uint8_t *buf, uint64_t n, int kind, uint64_t seed, uint64_t piece_bytes, int threads);
 
+/* Where every chunk of a stream that several GPUs compress goes: d_offsets[i] = base + the sum of d_lengths[0..i),
+ * d_offsets[n] = base + the sum of all (device arrays; d_offsets has n + 1 entries and must not be d_lengths).  A
+ * serial writer accumulates these in total_out as it flushes (deflate.c:642-662); ranks that compress shards side by
+ * side all-gather their chunks' lengths (d_chunk_off[i + 1] - d_chunk_off[i] of their own calls) and scan them here. */
+int zamd_chunk_offsets_dev(zamd_engine *e, const uint64_t *d_lengths, uint64_t n, uint64_t base, uint64_t *d_offsets);
+
 /* `fn(arg)` is called from inside every following deflate call of this engine, on the calling thread, when the call's last
  * kernel has been queued and before the call starts to wait for the GPU (NULL: no call).  A copy between pageable host
  * memory and the device holds a lock of the GPU runtime for its whole length, and kernel launches of other threads

@@ -341,3 +341,19 @@ def test_partial_flush_and_block_in_the_middle_of_a_stream(engine, flush):
     b, _ = engine.deflate_chunks(data[cut:], level=6, chunk_size=65536, finish=True, dictionary=data[cut - 32768:cut])
     # the second call's first byte holds the leftover bits in its low end: it replaces nothing of the first call
     assert zlib.decompress(a + b, -15) == data
+
+
+@pytest.mark.parametrize("n,base", [(1, 0), (7, 5), (1024, 0), (1025, 1 << 40), (70001, 123)])
+def test_chunk_offsets_scan(engine, n, base):
+    """zamd_chunk_offsets_dev: where the chunks of ranks that compress side by side go (the total_out a serial writer
+    accumulates, deflate.c:642-662)."""
+    import numpy as np
+    rng = np.random.default_rng(n)
+    lens = rng.integers(0, 1 << 21, size=n, dtype=np.uint64)
+    d_len = engine.alloc(8 * n); d_len.upload(lens.tobytes())
+    d_off = engine.alloc(8 * (n + 1))
+    engine.chunk_offsets(d_len.ptr, n, d_off.ptr, base)
+    got = np.frombuffer(bytes(d_off.download(8 * (n + 1))), dtype=np.uint64)
+    want = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64) + np.uint64(base)
+    assert (got == want).all()
+    d_len.free(); d_off.free()

@@ -57,6 +57,8 @@ def load_library() -> C.CDLL:
     lib.zamd_deflate_dev.restype = i32
     lib.zamd_deflate_shard_dev.argtypes = [vp, vp, u64, u32, u32, i32, i32, i32, i32, vp, u64, vp, C.POINTER(u64)]
     lib.zamd_deflate_shard_dev.restype = i32
+    lib.zamd_chunk_offsets_dev.argtypes = [vp, vp, u64, u64, vp]
+    lib.zamd_chunk_offsets_dev.restype = i32
     lib.zamd_engine_tune.argtypes = [vp, i32, i32, i32, i32]
     lib.zamd_engine_tune.restype = i32
     lib.zamd_find_sync_dev.argtypes = [vp, vp, u64, u64, C.POINTER(u64), C.c_uint32, C.POINTER(C.c_uint32)]
@@ -341,6 +343,10 @@ class Engine:
         if rc == Z_DATA_ERROR:
             raise self._inflate_error(rc, "zamd_inflate_dev")
         _chk(rc, "zamd_inflate_dev")
+
+    def chunk_offsets(self, d_lengths: int, n: int, d_offsets: int, base: int = 0) -> None:
+        """Exclusive scan of n uint64 chunk lengths on the device into n + 1 offsets (the last one is the total)."""
+        _chk(self.lib.zamd_chunk_offsets_dev(self.handle, d_lengths, n, base, d_offsets), "zamd_chunk_offsets_dev")
 
     def set_streams(self, nstreams: int = 4, serialize: bool = False) -> None:
         """Batches a deflate call keeps in flight; serialize: same batches on one stream (per-kernel timing)."""

@@ -1589,6 +1589,32 @@ extern "C" int zamd_crc32_dev(zamd_engine *e, uint32_t crc, const void *d_in, ui
 #include "zamd_fast_impl.h"
 
 /* ------------------------------------------------------------------ device-memory helpers */
+/* Exclusive scan of n chunk lengths on top of `base`: off[i] = base + len[0] + ... + len[i-1], off[n] = the total. */
+__global__ __launch_bounds__(1024) void k_offsets(const uint64_t *len, uint64_t n, uint64_t base, uint64_t *off)
+{
+    __shared__ uint64_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t per = (n + 1023) / 1024;
+    uint64_t sum = 0;
+    for (uint64_t k = 0; k < per; k++) { const uint64_t i = tid * per + k; if (i < n) sum += len[i]; }
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { uint64_t run = base; for (uint32_t i = 0; i < 1024; i++) { const uint64_t v = part[i]; part[i] = run; run += v; } off[n] = run; }
+    __syncthreads();
+    uint64_t run = part[tid];
+    for (uint64_t k = 0; k < per; k++) { const uint64_t i = tid * per + k; if (i < n) { off[i] = run; run += len[i]; } }
+}
+
+extern "C" int zamd_chunk_offsets_dev(zamd_engine *e, const uint64_t *d_lengths, uint64_t n, uint64_t base, uint64_t *d_offsets)
+{
+    if (!e || !d_lengths || !d_offsets || d_lengths == d_offsets) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(1024), 0, e->st[0], d_lengths, n, base, d_offsets);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->st[0]));
+    return ZAMD_OK;
+}
+
 extern "C" int zamd_engine_on_launched(zamd_engine *e, void (*fn)(void *), void *arg)
 {
     if (!e) return ZAMD_STREAM_ERROR;
