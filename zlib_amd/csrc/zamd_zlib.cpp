@@ -454,6 +454,14 @@ int finish_batch(z_streamp strm, DState *s, int flush, bool compressed = false) 
     return Z_OK;
 }
 
+// No exception leaves the library: the host-side buffers are std::vectors, and an allocation that fails inside one
+// of them comes back as Z_MEM_ERROR, as a failing zalloc does in the reference.
+template <class F> int guarded(z_streamp strm, F f) {
+    try { return f(); }
+    catch (const std::bad_alloc &) { if (strm) strm->msg = err_msg(Z_MEM_ERROR); return Z_MEM_ERROR; }
+    catch (...) { if (strm) strm->msg = err_msg(Z_STREAM_ERROR); return Z_STREAM_ERROR; }
+}
+
 }  // namespace
 
 extern "C" {
@@ -553,7 +561,7 @@ int deflatePending(z_streamp strm, unsigned *pending, int *bits) {
     return Z_OK;
 }
 
-int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength) {    // deflate.c:323-389
+static int deflateSetDictionary_body(z_streamp strm, const Bytef *dictionary, uInt dictLength) {    // deflate.c:323-389
     DState *s = dstate(strm);
     if (!s || dictionary == Z_NULL) return Z_STREAM_ERROR;
     if (s->wrap == 2 || (s->wrap == 1 && s->status != ST_INIT) || !s->in.empty() || s->since_reset != 0) return Z_STREAM_ERROR;
@@ -568,6 +576,7 @@ int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
     s->hist_len = keep;
     return Z_OK;
 }
+int deflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength) { return guarded(strm, [&] { return deflateSetDictionary_body(strm, dictionary, dictLength); }); }
 int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain) {    // deflate.c:531-547
     DState *s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
@@ -583,7 +592,7 @@ int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, 
     s->tuned = true;
     return Z_OK;
 }
-int deflatePrime(z_streamp strm, int bits, int value) {     // deflate.c:464-487
+static int deflatePrime_body(z_streamp strm, int bits, int value) {     // deflate.c:464-487
     DState *s = dstate(strm);
     if (!s || bits < 0 || bits > 32) return Z_STREAM_ERROR;
     // whole bytes go to the pending output at once (_tr_flush_bits, trees.c:882-886), the rest
@@ -595,8 +604,9 @@ int deflatePrime(z_streamp strm, int bits, int value) {     // deflate.c:464-487
     s->index_ok = false;                   // inserted bits are not part of any chunk
     return Z_OK;
 }
+int deflatePrime(z_streamp strm, int bits, int value) { return guarded(strm, [&] { return deflatePrime_body(strm, bits, value); }); }
 
-int deflateParams(z_streamp strm, int level, int strategy) {
+static int deflateParams_body(z_streamp strm, int level, int strategy) {
     DState *s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
     if (level == Z_DEFAULT_COMPRESSION) level = 6;
@@ -617,6 +627,7 @@ int deflateParams(z_streamp strm, int level, int strategy) {
     s->strategy = strategy;
     return err;
 }
+int deflateParams(z_streamp strm, int level, int strategy) { return guarded(strm, [&] { return deflateParams_body(strm, level, strategy); }); }
 
 uLong deflateBound(z_streamp strm, uLong sourceLen) {
     DState *s = dstate(strm);
@@ -643,7 +654,7 @@ uLong deflateBound(z_streamp strm, uLong sourceLen) {
     return body + wraplen;
 }
 
-int deflate(z_streamp strm, int flush) {
+static int deflate_body(z_streamp strm, int flush) {
     DState *s = dstate(strm);
     if (!s || flush > Z_BLOCK || flush < 0) return Z_STREAM_ERROR;
     if (strm->next_out == Z_NULL || (strm->next_in == Z_NULL && strm->avail_in != 0) ||
@@ -712,6 +723,7 @@ int deflate(z_streamp strm, int flush) {
     if (s->out.size() != s->out_pos) { s->last_flush = -1; return Z_OK; }
     return Z_STREAM_END;
 }
+int deflate(z_streamp strm, int flush) { return guarded(strm, [&] { return deflate_body(strm, flush); }); }
 
 int deflateEnd(z_streamp strm) {
     DState *s = dstate(strm);
@@ -725,7 +737,7 @@ int deflateEnd(z_streamp strm) {
     return status == ST_BUSY ? Z_DATA_ERROR : Z_OK;      // deflate.c:1006
 }
 
-int deflateCopy(z_streamp dest, z_streamp source) {
+static int deflateCopy_body(z_streamp dest, z_streamp source) {
     DState *ss = dstate(source);
     if (!ss || dest == Z_NULL) return Z_STREAM_ERROR;
     memcpy((void *)dest, (const void *)source, sizeof(z_stream));
@@ -735,6 +747,7 @@ int deflateCopy(z_streamp dest, z_streamp source) {
     dest->state = (struct internal_state *)ds;
     return Z_OK;
 }
+int deflateCopy(z_streamp dest, z_streamp source) { return guarded(dest, [&] { return deflateCopy_body(dest, source); }); }
 
 // Chunk index of the stream being written (no counterpart in the reference; the access points of
 // examples/zran.c:67-72 serve the same end): one entry per chunk, in stream order.
@@ -1250,7 +1263,7 @@ int inflateEnd(z_streamp strm) {
     return Z_OK;
 }
 
-int inflate(z_streamp strm, int flush) {
+static int inflate_body(z_streamp strm, int flush) {
     IState *s = istate(strm);
     if (!s || strm->next_out == Z_NULL || (strm->next_in == Z_NULL && strm->avail_in != 0)) return Z_STREAM_ERROR;
     if (s->mode == IM_MEM) return Z_MEM_ERROR;
@@ -1342,8 +1355,9 @@ int inflate(z_streamp strm, int flush) {
     if (((in0 == strm->avail_in && out0 == strm->avail_out) || flush == Z_FINISH) && ret == Z_OK) ret = Z_BUF_ERROR;
     return ret;
 }
+int inflate(z_streamp strm, int flush) { return guarded(strm, [&] { return inflate_body(strm, flush); }); }
 
-int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength) {
+static int inflateSetDictionary_body(z_streamp strm, const Bytef *dictionary, uInt dictLength) {
     IState *s = istate(strm);
     if (!s || (dictionary == Z_NULL && dictLength)) return Z_STREAM_ERROR;
     if (s->wrap != 0 && s->mode != IM_DICT) return Z_STREAM_ERROR;
@@ -1357,11 +1371,12 @@ int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLengt
     s->havedict = true;
     return Z_OK;
 }
+int inflateSetDictionary(z_streamp strm, const Bytef *dictionary, uInt dictLength) { return guarded(strm, [&] { return inflateSetDictionary_body(strm, dictionary, dictLength); }); }
 
 // The chunk index of the deflate data that follows (entries as zamd_deflate_index_get hands them out):
 // inflate() then places whole chunks directly instead of searching for their boundaries.  A hint that
 // does not fit the data costs time, not correctness: it is dropped and the data decoded without it.
-int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_chunks) {
+static int zamd_inflate_index_hint_body(z_streamp strm, const unsigned *pairs, unsigned n_chunks) {
     IState *s = istate(strm);
     if (!s || (pairs == Z_NULL && n_chunks)) return Z_STREAM_ERROR;
     if (s->mode != IM_HEAD && !(s->mode == IM_BODY && s->total == 0 && s->in.empty())) return Z_STREAM_ERROR;
@@ -1369,6 +1384,7 @@ int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_ch
     s->hint_pos = 0;
     return Z_OK;
 }
+int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_chunks) { return guarded(strm, [&] { return zamd_inflate_index_hint_body(strm, pairs, n_chunks); }); }
 
 int inflateGetDictionary(z_streamp strm, Bytef *dictionary, uInt *dictLength) {
     IState *s = istate(strm);
@@ -1418,7 +1434,7 @@ int inflateSyncPoint(z_streamp strm) {
     return 0;      // input is only ever consumed in whole blocks, never up to the length bytes of a stored block
 }
 
-int inflateCopy(z_streamp dest, z_streamp source) {
+static int inflateCopy_body(z_streamp dest, z_streamp source) {
     IState *ss = istate(source);
     if (dest == Z_NULL || !ss || source->zalloc == (alloc_func)0 || source->zfree == (free_func)0) return Z_STREAM_ERROR;
     void *mem = source->zalloc(source->opaque, 1, (uInt)sizeof(IState));
@@ -1428,6 +1444,7 @@ int inflateCopy(z_streamp dest, z_streamp source) {
     dest->state = (struct internal_state *)ds;
     return Z_OK;
 }
+int inflateCopy(z_streamp dest, z_streamp source) { return guarded(dest, [&] { return inflateCopy_body(dest, source); }); }
 
 int inflatePrime(z_streamp strm, int bits, int value) {     // inflate.c:230-250
     IState *s = istate(strm);
@@ -1593,7 +1610,7 @@ int inflateBackInit_(z_streamp strm, int windowBits, unsigned char *window, cons
     return Z_OK;
 }
 
-int inflateBack(z_streamp strm, in_func in, void *in_desc, out_func out, void *out_desc) {             // infback.c:250-629
+static int inflateBack_body(z_streamp strm, in_func in, void *in_desc, out_func out, void *out_desc) {             // infback.c:250-629
     if (strm == Z_NULL || strm->state == Z_NULL || ((BState *)strm->state)->magic != BACK_MAGIC) return Z_STREAM_ERROR;
     BState *b = (BState *)strm->state;
     strm->msg = Z_NULL;
@@ -1629,6 +1646,7 @@ int inflateBack(z_streamp strm, in_func in, void *in_desc, out_func out, void *o
     inflateEnd(&z);
     return ret;
 }
+int inflateBack(z_streamp strm, in_func in, void *in_desc, out_func out, void *out_desc) { return guarded(strm, [&] { return inflateBack_body(strm, in, in_desc, out, out_desc); }); }
 
 int inflateBackEnd(z_streamp strm) {                                                                    // infback.c:631-640
     if (strm == Z_NULL || strm->state == Z_NULL || strm->zfree == (free_func)0 || ((BState *)strm->state)->magic != BACK_MAGIC)
