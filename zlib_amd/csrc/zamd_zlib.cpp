@@ -74,6 +74,12 @@ int grow(zamd_engine *e, uint8_t **p, uint64_t *cap, uint64_t need) {
     return Z_OK;
 }
 
+// Large downloads go through the engine's pinned staging (copy engine and host memcpy overlapped: 25 GB/s where the
+// runtime's path for pageable memory gives 16).
+int download(zamd_engine *e, void *h_dst, const void *d_src, uint64_t bytes) {
+    return bytes >= (32u << 20) ? zamd_dev_download_staged(e, h_dst, d_src, bytes) : zamd_dev_download(e, h_dst, d_src, bytes);
+}
+
 uint64_t env_u64(const char *name, uint64_t dflt) {
     const char *v = getenv(name);
     if (!v || !*v) return dflt;
@@ -327,12 +333,12 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
     if (rc == 0 && b.total) {
         if (s->out.size() == s->out_pos && strm->avail_out >= b.total) {
             // nothing pending and room enough: straight into the caller's buffer
-            rc = zamd_dev_download(e, strm->next_out, g_gpu.d_out, b.total);
+            rc = download(e, strm->next_out, g_gpu.d_out, b.total);
             if (rc == 0) { strm->next_out += b.total; strm->avail_out -= (uInt)b.total; strm->total_out += b.total; }
         } else {
             size_t at = s->out.size();
             s->out.resize(at + b.total);
-            rc = zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, b.total);
+            rc = download(e, s->out.data() + at, g_gpu.d_out, b.total);
         }
     }
     tr.lap("download"); tr.done("deflate batch");
@@ -935,6 +941,9 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     if (zamd_dev_upload(e, g_gpu.d_in, ip, in_n) != 0) return Z_MEM_ERROR;
     tr.lap("upload");
     const uint64_t end_bits = in_n * 8ull;
+    // what a round may produce: the output batch, or what the caller's buffer takes when the round can write straight into it
+    uint64_t out_batch = s->out_batch;
+    if (s->out.size() == s->out_pos && strm->avail_out >= (64u << 20) && strm->avail_out < out_batch) out_batch = strm->avail_out;
     std::vector<zamd_inflate_seg> chain;
     uint64_t produced = 0, end_bit = s->bit_off;
     bool final_block = false;
@@ -947,7 +956,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         uint64_t pos = 0;
         for (size_t h = s->hint_pos; h + 1 < s->hints.size() && chain.size() < 8192; h += 2) {
             const uint64_t clen = s->hints[h], raw = s->hints[h + 1];
-            if (raw == 0 || pos + clen > in_n || (produced + raw > s->out_batch && !chain.empty())) break;
+            if (raw == 0 || pos + clen > in_n || (produced + raw > out_batch && !chain.empty())) break;
             zamd_inflate_seg g; memset(&g, 0, sizeof g);
             g.in_bit = pos * 8; g.in_end_bit = (pos + clen) * 8; g.out_off = produced; g.out_cap = raw; g.out_len = raw;
             g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
@@ -957,7 +966,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         }
         hinted = !chain.empty();
         if (hinted) end_bit = pos * 8;
-        else if (s->hints[s->hint_pos + 1] != 0 && s->hints[s->hint_pos + 1] <= s->out_batch) {
+        else if (s->hints[s->hint_pos + 1] != 0 && s->hints[s->hint_pos + 1] <= out_batch) {
             // the next chunk is not whole in the input yet: wait for the rest rather than leave the chunk grid
             if (view) return NO_PROGRESS;
             s->tried = in_n;
@@ -1082,14 +1091,14 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         size_t idx = 0;
         for (;;) {
             zamd_inflate_seg g = segs[idx];
-            if (g.out_len > s->out_batch && g.out_len > 0 && chain.empty()) {
+            if (g.out_len > out_batch && g.out_len > 0 && chain.empty()) {
                 // one segment larger than the output batch: take a whole-block prefix of it
-                zamd_inflate_seg one = g; one.out_cap = s->out_batch; one.status = 0;
+                zamd_inflate_seg one = g; one.out_cap = out_batch; one.status = 0;
                 if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, &one, 1, nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
                 if (one.out_len == 0) { strm->msg = "deflate block too large for the GPU engine"; s->mode = IM_MEM; return Z_MEM_ERROR; }
                 g = one; g.status = 3;
             }
-            if ((produced + g.out_len > s->out_batch || chain.size() >= 32768) && !chain.empty()) break;
+            if ((produced + g.out_len > out_batch || chain.size() >= 32768) && !chain.empty()) break;
             if (g.end_bit > g.in_bit || g.status == 1) {
                 g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
                 g.out_off = produced; g.out_cap = g.out_len; g.in_end_bit = g.end_bit; g.mode = ZAMD_INF_EXACT;
@@ -1149,13 +1158,13 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         const uint8_t *got;
         if (s->out.size() == s->out_pos && strm->avail_out >= produced) {
             // nothing pending and room enough: straight into the caller's buffer
-            if (zamd_dev_download(e, strm->next_out, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
+            if (download(e, strm->next_out, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
             got = strm->next_out;
             strm->next_out += produced; strm->avail_out -= (uInt)produced; strm->total_out += produced;
         } else {
             size_t at = s->out.size();
             s->out.resize(at + produced);
-            if (zamd_dev_download(e, s->out.data() + at, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
+            if (download(e, s->out.data() + at, g_gpu.d_out, produced) != 0) return Z_MEM_ERROR;
             got = s->out.data() + at;
         }
         tr.lap("download");
@@ -1240,7 +1249,9 @@ int inflateInit2_(z_streamp strm, int windowBits, const char *version, int strea
     if (mem == Z_NULL) return Z_MEM_ERROR;
     IState *s = new (mem) IState();
     s->magic = INFLATE_MAGIC;
-    s->out_batch = env_u64("ZAMD_Z_OUT_BATCH_MIB", 1024) << 20;
+    // A round costs what its slowest segment costs, however many segments it has (up to the GPU's 6 000 wavefront
+    // slots): large rounds are cheap rounds.
+    s->out_batch = env_u64("ZAMD_Z_OUT_BATCH_MIB", 4096) << 20;
     strm->state = (struct internal_state *)s;
     int ret = inflateReset2(strm, windowBits);
     if (ret != Z_OK) {
@@ -1326,7 +1337,8 @@ static int inflate_body(z_streamp strm, int flush) {
             bool tried_all = false;
             if (s->in.empty() && strm->avail_in >= (1u << 20)) {
                 // a large input is decoded where it lies; what a round does not use stays with the caller
-                const size_t n = strm->avail_in < (512u << 20) ? strm->avail_in : (512u << 20);
+                static const size_t view_cap = (size_t)env_u64("ZAMD_Z_IN_VIEW_MIB", 2048) << 20;
+                const size_t n = strm->avail_in < view_cap ? strm->avail_in : view_cap;
                 int rc = decode_some(strm, s, strm->next_in, n);
                 if (rc == Z_MEM_ERROR) { s->mode = IM_MEM; return Z_MEM_ERROR; }
                 if (rc != NO_PROGRESS) continue;
