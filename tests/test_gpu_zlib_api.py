@@ -551,6 +551,48 @@ def test_state_goes_through_the_callers_allocator():
         assert init(z) == Z.Z_MEM_ERROR and not z.state
 
 
+def test_a_callers_memory_limit_bounds_the_buffers_too():
+    """The mem_limit idea of test/infcover.c:55-234: an allocator that refuses beyond a budget.  The state's buffers
+    (input waiting for a full batch, output waiting for room) come from zalloc as well, so a stream that would
+    have to buffer more than the budget reports Z_MEM_ERROR instead of growing behind the caller's back, and
+    everything it did get goes back through zfree."""
+    l = Z.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    live, budget = {}, {"left": 3 << 20, "refused": 0}
+
+    def zalloc(opaque, items, size):
+        n = items * size
+        if n > budget["left"]:
+            budget["refused"] += 1
+            return None
+        p = libc.malloc(n)
+        live[p] = n; budget["left"] -= n
+        return p
+
+    def zfree(opaque, p):
+        budget["left"] += live.pop(p)
+        libc.free(p)
+
+    za, zf = Z.ALLOC(zalloc), Z.FREE(zfree)
+    data = O.corpus(8 << 20, 1, 141)                     # noise: the output is as large as the input
+    src = C.create_string_buffer(data, len(data))
+    obuf = C.create_string_buffer(1 << 16)
+    s = Z.ZStream()
+    s.zalloc, s.zfree = C.cast(za, C.c_void_p), C.cast(zf, C.c_void_p)
+    assert l.deflateInit2_(C.byref(s), 6, 8, -15, 8, 0, Z.VERSION, Z.SZ) == Z.Z_OK
+    rc, pos = Z.Z_OK, 0
+    while rc == Z.Z_OK and pos < len(data):               # 8 MiB of input in pieces: they wait in the state for a full batch
+        s.next_in, s.avail_in = C.addressof(src) + pos, 1 << 20
+        s.next_out, s.avail_out = C.addressof(obuf), 1 << 16
+        rc = l.deflate(C.byref(s), Z.Z_NO_FLUSH)
+        pos += (1 << 20) - s.avail_in
+    assert rc == Z.Z_MEM_ERROR and budget["refused"] >= 1 and pos < len(data)
+    l.deflateEnd(C.byref(s))
+    assert not live and budget["left"] == 3 << 20
+
+
 def test_streams_of_different_threads():
     """Distinct streams may be used from different threads at once (zlib.h:143-145); the one GPU engine behind
     them is shared under a lock."""

@@ -100,6 +100,29 @@ uint32_t header_crc(uint32_t crc, const uint8_t *p, size_t n) {
     return ~crc;
 }
 
+// The buffers of a stream's state come from the stream's own zalloc/zfree, like the state itself (a caller that
+// limits or counts memory through them, as test/infcover.c:55-234 does, then sees all of it).  zalloc takes 32-bit
+// items and sizes: requests are made in units of 64 KiB.
+template <class T> struct ZAlloc {
+    typedef T value_type;
+    alloc_func za; free_func zf; voidpf opaque;
+    ZAlloc() : za(default_alloc), zf(default_free), opaque(Z_NULL) {}
+    explicit ZAlloc(z_streamp strm) : za(strm->zalloc), zf(strm->zfree), opaque(strm->opaque) {}
+    template <class U> ZAlloc(const ZAlloc<U> &o) : za(o.za), zf(o.zf), opaque(o.opaque) {}
+    T *allocate(size_t n) {
+        const uint64_t bytes = (uint64_t)n * sizeof(T);
+        void *p = bytes <= 65536 ? za(opaque, 1, (uInt)(bytes ? bytes : 1)) : za(opaque, (uInt)((bytes + 65535) >> 16), 65536);
+        if (p == Z_NULL) throw std::bad_alloc();
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) { zf(opaque, p); }
+    template <class U> bool operator==(const ZAlloc<U> &o) const { return za == o.za && zf == o.zf && opaque == o.opaque; }
+    template <class U> bool operator!=(const ZAlloc<U> &o) const { return !(*this == o); }
+};
+typedef std::vector<uint8_t, ZAlloc<uint8_t>> Bytes;
+typedef std::vector<uint32_t, ZAlloc<uint32_t>> Words;
+typedef std::vector<uint64_t, ZAlloc<uint64_t>> Longs;
+
 const uint32_t DEFLATE_MAGIC = 0x5a414d44u;   // distinguishes our states from inflate states
 const uint32_t INFLATE_MAGIC = 0x5a414d49u;
 const uint32_t HIST = 32768;
@@ -130,12 +153,13 @@ struct DState {
     uint32_t dictid;
     uint32_t hist_len;                 // bytes of history kept in `hist` (== HIST once warm)
     uint64_t since_reset;              // input bytes compressed since the last history reset
-    std::vector<uint8_t> hist;         // last 32 KiB of compressed input
-    std::vector<uint8_t> in;           // input accepted from the caller, not yet compressed
-    std::vector<uint8_t> out;          // produced output not yet handed to the caller
+    Bytes hist;                        // last 32 KiB of compressed input
+    Bytes in;                          // input accepted from the caller, not yet compressed
+    Bytes out;                         // produced output not yet handed to the caller
     size_t out_pos;
     bool index_on, index_ok;           // chunk index wanted (zamd_deflate_index); still describes the whole stream
-    std::vector<uint32_t> index;       // per chunk since the last reset: compressed bytes, inflated bytes
+    Words index;                       // per chunk since the last reset: compressed bytes, inflated bytes
+    explicit DState(z_streamp strm) : hist(ZAlloc<uint8_t>(strm)), in(ZAlloc<uint8_t>(strm)), out(ZAlloc<uint8_t>(strm)), index(ZAlloc<uint32_t>(strm)) {}
 };
 
 inline DState *dstate(z_streamp strm) {
@@ -146,10 +170,10 @@ inline DState *dstate(z_streamp strm) {
 
 inline int rank_of(int f) { return (f << 1) - (f > 4 ? 9 : 0); }   // deflate.c:153
 
-void put_be32(std::vector<uint8_t> &v, uint32_t x) {
+void put_be32(Bytes &v, uint32_t x) {
     v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
 }
-void put_le32(std::vector<uint8_t> &v, uint32_t x) {
+void put_le32(Bytes &v, uint32_t x) {
     v.push_back(x); v.push_back(x >> 8); v.push_back(x >> 16); v.push_back(x >> 24);
 }
 
@@ -164,7 +188,7 @@ void flush_pending(z_streamp strm, DState *s) {    // deflate.c:642-662
 }
 
 void write_header(z_streamp strm, DState *s) {     // deflate.c:690-867
-    std::vector<uint8_t> &o = s->out;
+    Bytes &o = s->out;
     int xfl = s->level == 9 ? 2 : ((s->strategy >= Z_HUFFMAN_ONLY || s->level < 2) ? 4 : 0);
     if (s->wrap == 2) {
         size_t beg = o.size();
@@ -510,7 +534,7 @@ int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int mem
     if (level == 0 && (strategy == Z_HUFFMAN_ONLY || strategy == Z_RLE)) { strm->msg = "parameter not supported by the GPU engine"; return Z_STREAM_ERROR; }
     void *mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(DState));
     if (mem == Z_NULL) return Z_MEM_ERROR;
-    DState *s = new (mem) DState();
+    DState *s = new (mem) DState(strm);
     s->magic = DEFLATE_MAGIC;
     s->wrap = wrap; s->level = level; s->strategy = strategy; s->mem_level = memLevel; s->w_bits = windowBits;
     s->gzhead = Z_NULL;
@@ -789,20 +813,22 @@ struct IState {
     IMode mode;
     bool gzip, havedict, last, synced;
     gz_headerp head;
-    std::vector<uint8_t> hdr;       // wrapper header bytes seen so far
-    std::vector<uint8_t> in;        // compressed bytes from the next block start on
+    Bytes hdr;                      // wrapper header bytes seen so far
+    Bytes in;                       // compressed bytes from the next block start on
     uint32_t bit_off;               // bit inside in[0] where that block starts
     size_t scanned;                 // in[0, scanned) has been searched for sync markers
     size_t tried;                   // size of `in` at the last attempt that made no progress
-    std::vector<uint64_t> cands;    // byte offsets in `in` just behind a 00 00 FF FF pattern
-    std::vector<uint8_t> out; size_t out_pos;
-    std::vector<uint8_t> hist;      // last <= 32 KiB of output (the window)
+    Longs cands;                    // byte offsets in `in` just behind a 00 00 FF FF pattern
+    Bytes out; size_t out_pos;
+    Bytes hist;                     // last <= 32 KiB of output (the window)
     uint32_t check; uint64_t total; // running check value and length of the inflated data
     uint32_t dictid;
     uint64_t out_batch;
     uint64_t prime_hold; unsigned prime_bits;   // inflatePrime bits waiting in front of the first input byte
-    std::vector<uint32_t> hints; size_t hint_pos;   // chunk index of the deflate data ahead (zamd_inflate_index_hint): compressed bytes, inflated bytes per chunk
+    Words hints; size_t hint_pos;   // chunk index of the deflate data ahead (zamd_inflate_index_hint): compressed bytes, inflated bytes per chunk
     size_t call_taken;              // bytes the current inflate() call has moved from next_in to the end of `in`
+    explicit IState(z_streamp strm) : hdr(ZAlloc<uint8_t>(strm)), in(ZAlloc<uint8_t>(strm)), cands(ZAlloc<uint64_t>(strm)), out(ZAlloc<uint8_t>(strm)),
+                                      hist(ZAlloc<uint8_t>(strm)), hints(ZAlloc<uint32_t>(strm)) {}
 };
 
 // Hands the bytes at the end of `in` that the current call took (at most `want` of them) back to the caller.
@@ -831,7 +857,7 @@ int ibad(z_streamp strm, IState *s, const char *msg) { strm->msg = msg; s->mode 
 // Parses the wrapper header collected in s->hdr.  Returns 1 when complete, 0 when
 // more bytes are needed, Z_DATA_ERROR on a bad header (msg set).  (inflate.c:640-825)
 int parse_header(z_streamp strm, IState *s) {
-    const std::vector<uint8_t> &h = s->hdr;
+    const Bytes &h = s->hdr;
     size_t n = h.size();
     if (n < 2) return 0;
     if ((s->wrap & 2) && h[0] == 0x1f && h[1] == 0x8b) {
@@ -929,8 +955,8 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     const bool view = ext != nullptr;
     const uint8_t *const ip = view ? ext : s->in.data();
     const size_t in_n = view ? ext_n : s->in.size();
-    std::vector<uint64_t> view_cands; size_t view_scanned = 0;
-    std::vector<uint64_t> &cands = view ? view_cands : s->cands;
+    Longs view_cands(s->cands.get_allocator()); size_t view_scanned = 0;
+    Longs &cands = view ? view_cands : s->cands;
     size_t &scanned = view ? view_scanned : s->scanned;
     if (in_n * 8ull <= s->bit_off) return view ? NO_PROGRESS : Z_OK;
     Trace tr;
@@ -1185,7 +1211,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     if (view) { strm->next_in += drop; strm->avail_in -= (uInt)drop; strm->total_in += drop; }
     else {
         s->in.erase(s->in.begin(), s->in.begin() + drop);
-        std::vector<uint64_t> keep;
+        Longs keep(cands.get_allocator());
         for (uint64_t c : cands) if (c > drop) keep.push_back(c - drop);
         cands.swap(keep);
         scanned = scanned > drop ? scanned - drop : 0;
@@ -1247,7 +1273,7 @@ int inflateInit2_(z_streamp strm, int windowBits, const char *version, int strea
     if (strm->zfree == (free_func)0) strm->zfree = default_free;
     void *mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(IState));
     if (mem == Z_NULL) return Z_MEM_ERROR;
-    IState *s = new (mem) IState();
+    IState *s = new (mem) IState(strm);
     s->magic = INFLATE_MAGIC;
     // A round costs what its slowest segment costs, however many segments it has (up to the GPU's 6 000 wavefront
     // slots): large rounds are cheap rounds.
@@ -1419,7 +1445,7 @@ int inflateSync(z_streamp strm) {          // inflate.c:1377-1418
     if (!s) return Z_STREAM_ERROR;
     if (strm->avail_in == 0 && s->in.empty()) return Z_BUF_ERROR;
     // search the buffered bytes, then the caller's
-    std::vector<uint8_t> &b = s->in;
+    Bytes &b = s->in;
     size_t from = s->bit_off ? 1 : 0;
     b.insert(b.end(), strm->next_in, strm->next_in + strm->avail_in);
     size_t taken = strm->avail_in, found = 0;
@@ -1431,7 +1457,7 @@ int inflateSync(z_streamp strm) {          // inflate.c:1377-1418
     size_t behind = b.size() - found;
     size_t give = behind < taken ? behind : taken;
     strm->next_in -= give; strm->avail_in += (uInt)give; strm->total_in -= give;
-    std::vector<uint8_t> rest(b.begin() + found, b.end() - give);
+    Bytes rest(b.begin() + found, b.end() - give, b.get_allocator());
     uLong tin = strm->total_in, tout = strm->total_out;
     istate_reset(strm, s, false);
     strm->total_in = tin; strm->total_out = tout;
