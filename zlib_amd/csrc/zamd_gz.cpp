@@ -96,7 +96,7 @@ unsigned default_want()
     return (unsigned)(mib << 20);
 }
 
-gzFile open_file(const char *path, int fd, const char *mode)      /* gz_open, gzlib.c:91-265 */
+static gzFile open_file_body(const char *path, int fd, const char *mode)      /* gz_open, gzlib.c:91-265 */
 {
     if (path == NULL) return NULL;
     GzFile *s = new (std::nothrow) GzFile();
@@ -162,6 +162,11 @@ gzFile open_file(const char *path, int fd, const char *mode)      /* gz_open, gz
     }
     reset(s);
     return (gzFile)s;
+}
+gzFile open_file(const char *path, int fd, const char *mode)
+{
+    try { return open_file_body(path, fd, mode); }
+    catch (...) { return NULL; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
 }
 
 /* ------------------------------------------------------------------ reading */
@@ -497,7 +502,7 @@ int gzrewind(gzFile file)                                                       
     return 0;
 }
 
-z_off64_t gzseek64(gzFile file, z_off64_t offset, int whence)                                   /* gzlib.c:362-436 */
+static z_off64_t gzseek64_body(gzFile file, z_off64_t offset, int whence)                                   /* gzlib.c:362-436 */
 {
     GzFile *s = gz(file);
     if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE) || fatal(s)) return -1;
@@ -525,6 +530,11 @@ z_off64_t gzseek64(gzFile file, z_off64_t offset, int whence)                   
     }
     if (offset) { s->seek = 1; s->skip = offset; }
     return s->x.pos + offset;
+}
+z_off64_t gzseek64(gzFile file, z_off64_t offset, int whence)
+{
+    try { return gzseek64_body(file, offset, whence); }
+    catch (...) { return -1; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
 }
 
 z_off_t gzseek(gzFile file, z_off_t offset, int whence)
@@ -576,7 +586,7 @@ void gzclearerr(gzFile file)                                                    
 }
 
 /* ------------------------------------------------------------------ gzread.c */
-int gzread(gzFile file, voidp buf, unsigned len)                                                /* gzread.c:288-379 */
+static int gzread_body(gzFile file, voidp buf, unsigned len)                                                /* gzread.c:288-379 */
 {
     GzFile *s = gz(file);
     if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
@@ -605,9 +615,14 @@ int gzread(gzFile file, voidp buf, unsigned len)                                
     } while (len);
     return (int)got;
 }
+int gzread(gzFile file, voidp buf, unsigned len)
+{
+    try { return gzread_body(file, buf, len); }
+    catch (...) { return -1; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
 #undef gzgetc
-int gzgetc(gzFile file)                                                                         /* gzread.c:387-414 */
+static int gzgetc_body(gzFile file)                                                                         /* gzread.c:387-414 */
 {
     GzFile *s = gz(file);
     if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
@@ -615,9 +630,14 @@ int gzgetc(gzFile file)                                                         
     unsigned char c;
     return gzread(file, &c, 1) < 1 ? -1 : c;
 }
+int gzgetc(gzFile file)
+{
+    try { return gzgetc_body(file); }
+    catch (...) { return -1; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 int gzgetc_(gzFile file) { return gzgetc(file); }
 
-int gzungetc(int c, gzFile file)                                                                /* gzread.c:423-480 */
+static int gzungetc_body(int c, gzFile file)                                                                /* gzread.c:423-480 */
 {
     GzFile *s = gz(file);
     if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
@@ -640,8 +660,13 @@ int gzungetc(int c, gzFile file)                                                
     s->x.pos--; s->past = 0;
     return c;
 }
+int gzungetc(int c, gzFile file)
+{
+    try { return gzungetc_body(c, file); }
+    catch (...) { return -1; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
-char *gzgets(gzFile file, char *buf, int len)                                                   /* gzread.c:483-544 */
+static char *gzgets_body(gzFile file, char *buf, int len)                                                   /* gzread.c:483-544 */
 {
     GzFile *s = gz(file);
     if (s == NULL || buf == NULL || len < 1) return NULL;
@@ -663,6 +688,11 @@ char *gzgets(gzFile file, char *buf, int len)                                   
     buf[0] = 0;
     return str;
 }
+char *gzgets(gzFile file, char *buf, int len)
+{
+    try { return gzgets_body(file, buf, len); }
+    catch (...) { return NULL; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
 int gzdirect(gzFile file)                                                                       /* gzread.c:547-564 */
 {
@@ -672,7 +702,7 @@ int gzdirect(gzFile file)                                                       
     return s->direct;
 }
 
-int gzclose_r(gzFile file)                                                                      /* gzread.c:567-594 */
+static int gzclose_r_body(gzFile file)                                                                      /* gzread.c:567-594 */
 {
     GzFile *s = gz(file);
     if (s == NULL) return Z_STREAM_ERROR;
@@ -683,9 +713,14 @@ int gzclose_r(gzFile file)                                                      
     delete s;
     return ret ? Z_ERRNO : err;
 }
+int gzclose_r(gzFile file)
+{
+    try { return gzclose_r_body(file); }
+    catch (...) { return Z_MEM_ERROR; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
 /* ------------------------------------------------------------------ gzwrite.c */
-int gzwrite(gzFile file, const void *buf, unsigned len)                                         /* gzwrite.c:165-243 */
+static int gzwrite_body(gzFile file, const void *buf, unsigned len)                                         /* gzwrite.c:165-243 */
 {
     GzFile *s = gz(file);
     if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return 0;
@@ -714,6 +749,11 @@ int gzwrite(gzFile file, const void *buf, unsigned len)                         
     }
     return (int)put;
 }
+int gzwrite(gzFile file, const void *buf, unsigned len)
+{
+    try { return gzwrite_body(file, buf, len); }
+    catch (...) { return 0; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
 int gzputc(gzFile file, int c)                                                                  /* gzwrite.c:246-291 */
 {
@@ -730,7 +770,7 @@ int gzputs(gzFile file, const char *str)                                        
     return ret == 0 && len != 0 ? -1 : ret;
 }
 
-int gzvprintf(gzFile file, const char *format, va_list va)                                      /* gzwrite.c:311-373 */
+static int gzvprintf_body(gzFile file, const char *format, va_list va)                                      /* gzwrite.c:311-373 */
 {
     GzFile *s = gz(file);
     if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return 0;
@@ -746,6 +786,11 @@ int gzvprintf(gzFile file, const char *format, va_list va)                      
     s->x.pos += len;
     return len;
 }
+int gzvprintf(gzFile file, const char *format, va_list va)
+{
+    try { return gzvprintf_body(file, format, va); }
+    catch (...) { return 0; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
 int gzprintf(gzFile file, const char *format, ...)                                              /* gzwrite.c:375-385 */
 {
@@ -756,7 +801,7 @@ int gzprintf(gzFile file, const char *format, ...)                              
     return ret;
 }
 
-int gzflush(gzFile file, int flush)                                                             /* gzwrite.c:478-510 */
+static int gzflush_body(gzFile file, int flush)                                                             /* gzwrite.c:478-510 */
 {
     GzFile *s = gz(file);
     if (s == NULL) return -1;
@@ -766,8 +811,13 @@ int gzflush(gzFile file, int flush)                                             
     comp(s, flush);
     return s->err;
 }
+int gzflush(gzFile file, int flush)
+{
+    try { return gzflush_body(file, flush); }
+    catch (...) { return Z_MEM_ERROR; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
-int gzsetparams(gzFile file, int level, int strategy)                                           /* gzwrite.c:513-552 */
+static int gzsetparams_body(gzFile file, int level, int strategy)                                           /* gzwrite.c:513-552 */
 {
     GzFile *s = gz(file);
     if (s == NULL) return Z_STREAM_ERROR;
@@ -781,8 +831,13 @@ int gzsetparams(gzFile file, int level, int strategy)                           
     s->level = level; s->strategy = strategy;
     return Z_OK;
 }
+int gzsetparams(gzFile file, int level, int strategy)
+{
+    try { return gzsetparams_body(file, level, strategy); }
+    catch (...) { return Z_MEM_ERROR; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
+}
 
-int gzclose_w(gzFile file)                                                                      /* gzwrite.c:555-577 */
+static int gzclose_w_body(gzFile file)                                                                      /* gzwrite.c:555-577 */
 {
     GzFile *s = gz(file);
     if (s == NULL) return Z_STREAM_ERROR;
@@ -795,6 +850,11 @@ int gzclose_w(gzFile file)                                                      
     if (close(s->fd) == -1) ret = Z_ERRNO;
     delete s;
     return ret;
+}
+int gzclose_w(gzFile file)
+{
+    try { return gzclose_w_body(file); }
+    catch (...) { return Z_MEM_ERROR; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
 }
 
 int gzclose(gzFile file)                                                                        /* gzclose.c:11-25 */
