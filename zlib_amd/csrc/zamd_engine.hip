@@ -587,6 +587,62 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
     if (lane == 0) { J.nhop[lc] = H; if (nfall) atomicAdd(J.err + 1, nfall); }
 }
 
+/* The same walk for the hop words of k_resolve (no searches of its own), with the dependent LDS read taken off most
+ * hops: the 64 hop words from the current position on sit in one register, a hop inside them is a v_readlane and a
+ * few scalar instructions (the walk's state is wave-uniform: it lives in scalar registers), and the LDS is read once
+ * per window instead of once per hop.  Arrivals are kept one per lane and stored 64 at a time. */
+__global__ __launch_bounds__(64) void k_hopw(ZkJob J)
+{
+    __shared__ uint32_t s_tile[ZK_HOP_TILE];
+    const uint32_t lc = blockIdx.x, lane = threadIdx.x;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
+    const uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;
+    uint32_t *arr = J.arr + (uint64_t)lc * (J.P.chunk_size / 2);
+    const uint32_t len = __builtin_amdgcn_readfirstlane(g.len);
+    /* the hop words of one tile, eight per lane, on their way from memory: the tile behind the current one is fetched
+     * while the current one is walked */
+    auto fetch = [&](uint32_t tb, uint4 &v0, uint4 &v1) {
+        uint4 *v[2] = {&v0, &v1};
+#pragma unroll
+        for (uint32_t r = 0; r < 2; r++) {
+            const uint32_t idx = tb + r * 256u + lane * 4u;
+            uint4 q = make_uint4(1, 1, 1, 1);
+            if (idx + 4u <= len) q = *(const uint4 *)(hop + idx);
+            else { if (idx < len) q.x = hop[idx]; if (idx + 1 < len) q.y = hop[idx + 1]; if (idx + 2 < len) q.z = hop[idx + 2]; }
+            *v[r] = q;
+        }
+    };
+    uint32_t i = 0, H = 0, base = 0xffff0000u, pbase = 0xffff0000u, wb = 0, wlen = 0, w = 0, abuf = 0;
+    uint4 p0 = make_uint4(1, 1, 1, 1), p1 = p0;
+    while (i < len) {
+        if (i - base >= ZK_HOP_TILE) {
+            base = i & ~(ZK_HOP_TILE - 1u);
+            if (base != pbase) fetch(base, p0, p1);        /* the first tile, or a hop over a whole tile */
+            __syncthreads();
+            *(uint4 *)(s_tile + lane * 4u) = p0;
+            *(uint4 *)(s_tile + 256u + lane * 4u) = p1;
+            __syncthreads();
+            pbase = base + ZK_HOP_TILE;
+            if (pbase < len) fetch(pbase, p0, p1);
+            wlen = 0;
+        }
+        if (i - wb >= wlen) {
+            const uint32_t off = i - base;
+            wb = i; wlen = ZK_HOP_TILE - off < 64u ? ZK_HOP_TILE - off : 64u;
+            w = s_tile[off + lane < ZK_HOP_TILE ? off + lane : ZK_HOP_TILE - 1u];
+        }
+        const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)(i - wb));
+        if (h & ZC_HOP_MATCH) {
+            abuf = lane == (H & 63u) ? i : abuf;
+            if ((H & 63u) == 63u) arr[(H & ~63u) + lane] = abuf;
+            H++;
+            i += zc_hop_k(h) + zc_hop_len(h);
+        } else i += h;
+    }
+    if (lane < (H & 63u)) arr[(H & ~63u) + lane] = abuf;
+    if (lane == 0) J.nhop[lc] = H;
+}
+
 /* The same walk for the hop words of k_resolve, eight chunks to a wavefront.  The walk is serial per chunk and a lone
  * wavefront per chunk spends its 64 lanes on one chain of dependent LDS reads, so that what bounds the kernel is the
  * instruction issue of 32 such wavefronts per CU: here a group of eight lanes owns a chunk (its lanes carry identical
@@ -1408,7 +1464,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         else if (P.parser == ZC_PARSE_SLOW && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {
             const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
             if (dense) hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
-            if (dense) hipLaunchKernelGGL(k_hop<false>, dim3(J.nchunks), dim3(64), 0, s, J);
+            if (dense) hipLaunchKernelGGL(k_hopw, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_hop<true>, dim3(J.nchunks), dim3(64), 0, s, J);
             hipLaunchKernelGGL(k_expand, dim3(J.nchunks), dim3(ZK_EXPAND_THREADS), 0, s, J);
         } else hipLaunchKernelGGL(k_parse, dim3(J.nchunks), dim3(64), 0, s, J);
