@@ -1109,7 +1109,7 @@ struct ZeWorkspace {
     ZcBlock *blk = nullptr; ZcBlockTab *tab = nullptr;
     uint32_t *nblk = nullptr, *nsym = nullptr; uint64_t *chunk_bytes = nullptr, *sync_bit = nullptr;
     uint64_t pdist_len = 0;
-    uint16_t *fhead = nullptr; uint32_t fhead_chunks = 0;
+    uint16_t *fhead = nullptr; uint64_t fhead_bytes = 0;
 };
 
 #define ZE_STREAMS 8            /* batches in flight at most */
@@ -1349,7 +1349,9 @@ static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint
 }
 
 __global__ void k_fast(ZkJob J);
+__global__ void k_fastw(ZkJob J);
 #define ZF_ROW (65536u + 32768u)
+#define ZFW_WAYS 4u
 static void tm_begin(zamd_engine *e, hipStream_t s, int which, int *slot)
 {
     *slot = -1;
@@ -1453,13 +1455,18 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         }
         tm_begin(e, s, 2, &slot);
         if (P.parser == ZC_PARSE_FAST) {
-            if (w.fhead_chunks < batch) {
-                hipFree(w.fhead); w.fhead = nullptr; w.fhead_chunks = 0;
-                HIPCHK(hipMalloc((void **)&w.fhead, (uint64_t)batch * ZF_ROW * 2u)); w.fhead_chunks = batch;
+            /* a chain budget that fits a bucket of the newest strings per hash value needs no links (k_fastw) */
+            static const bool old_fast = getenv("ZAMD_FAST_LINKS") != nullptr;
+            const bool ways = P.chain <= ZFW_WAYS && !old_fast;
+            const uint64_t row = ways ? (uint64_t)(P.hash_mask + 1u) * 16u : (uint64_t)ZF_ROW * 2u;
+            if (w.fhead_bytes < batch * row) {
+                hipFree(w.fhead); w.fhead = nullptr; w.fhead_bytes = 0;
+                HIPCHK(hipMalloc((void **)&w.fhead, batch * row)); w.fhead_bytes = batch * row;
             }
             J.fhead = w.fhead;
-            HIPCHK(hipMemsetAsync(w.fhead, 0, (uint64_t)J.nchunks * ZF_ROW * 2u, s));
-            hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
+            HIPCHK(hipMemsetAsync(w.fhead, 0, J.nchunks * row, s));
+            if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
+            else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
         else if (P.parser == ZC_PARSE_SLOW && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {
             const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
