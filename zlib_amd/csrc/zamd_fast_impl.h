@@ -303,6 +303,10 @@ struct ZkFastWCtx {
     }
 };
 
+/* deflate_fast (deflate.c:1628-1722) written out for this table; the same steps as zc_parse_fast over ZkFastWCtx
+ * (which stays as the readable form and the fallback of a build with -DZFW_GENERIC), with every piece of the state
+ * machine kept wave-uniform in scalar registers. */
+#ifdef ZFW_GENERIC
 __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
 {
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
@@ -325,3 +329,174 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         J.nsym[lc] = nsym;
     }
 }
+#else
+#define ZFW_UNI(x) __builtin_amdgcn_readfirstlane(x)
+/* position of the lowest set bit, 0xffffffff for 0 (what the instruction returns; __builtin_ctz leaves 0 undefined) */
+__device__ __forceinline__ uint32_t zfw_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t zfw_min3(uint32_t a, uint32_t b, uint32_t c) { uint32_t m = a < b ? a : b; return m < c ? m : c; }
+/* a wave's own loads see its own earlier stores: order for the compiler, nothing for the hardware to wait for */
+#define ZFW_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
+
+__global__ __launch_bounds__(64) void k_fastw(ZkJob J)
+{
+    const uint32_t lc = blockIdx.x, lane = threadIdx.x;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
+    const uint8_t *const b = J.in + g.dstart;
+    const uint64_t readable = J.n - g.dstart;
+    const uint32_t dict_len = g.dict_len, E = g.dict_len + g.len;
+    uint4 *const tab = (uint4 *)J.fhead + (uint64_t)lc * (J.P.hash_mask + 1u);
+    const uint32_t hshift = J.P.hash_shift, hmask = J.P.hash_mask, nice = J.P.nice, max_dist = J.P.max_dist;
+    const uint32_t ways = J.P.chain < ZFW_WAYS ? J.P.chain : ZFW_WAYS;
+    const uint32_t W = J.P.wsize, max_insert = J.P.lazy, lim = J.P.lit_bufsize - 1u;
+    uint32_t *const symout = J.sym + (uint64_t)lc * J.P.chunk_size;
+    GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
+    /* a comparison may read 16 bytes at a time while 258 + 16 bytes from p on lie inside the buffer */
+    const uint32_t wide_end = readable > 274u ? (uint32_t)(readable - 274u < 0xfffffff0ull ? readable - 274u : 0xfffffff0ull) : 0u;
+    const bool is0 = lane == 0, is1 = lane == 1, is2 = lane == 2, in_ways = lane < ways;
+    const uint32_t inv_lane = 3u - lane;
+
+    /* ---- the batches: hashes and buckets of positions q0 .. q0 + 127, one position per lane and batch */
+    uint32_t q0 = 0, h_cur, h_nxt, last_cur = ZFW_NONE;
+    uint4 c_cur, c_nxt;
+    auto load_batch = [&](uint32_t qb, uint32_t &h, uint4 &c) {
+        const uint32_t a = qb + lane;
+        const bool ok = a + ZC_MIN_MATCH <= E;
+        uint32_t w = 0;
+        if (ok) {
+            if ((uint64_t)a + 4u <= readable) __builtin_memcpy(&w, b + a, 4);
+            else for (uint32_t i = 0; i < 4 && (uint64_t)a + i < readable; i++) w |= (uint32_t)b[a + i] << (8u * i);
+        }
+        h = ok ? zc_hash3(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, hshift, hmask) : ZFW_NONE;
+        c = make_uint4(0, 0, 0, 0);
+        if (ok) c = tab[h];
+    };
+    /* p has left the current batch: its insertions go to the table, the next batch takes its place */
+    auto advance = [&](uint32_t p) {
+        if (last_cur == lane) tab[h_cur] = c_cur;
+        last_cur = ZFW_NONE;
+        ZFW_WAVE_FENCE();
+        if (p - q0 < 128u) {
+            h_cur = h_nxt; c_cur = c_nxt; q0 += 64u;
+            load_batch(q0 + 64u, h_nxt, c_nxt);
+        } else {
+            q0 = p;
+            load_batch(q0, h_cur, c_cur);
+            load_batch(q0 + 64u, h_nxt, c_nxt);
+        }
+    };
+    /* INSERT_STRING (deflate.c:186-189): the string at p enters the buckets that later positions of the two batches
+     * hold for its hash value, and its own lane's, which becomes the table entry when the batch is left */
+    auto enter = [&](uint32_t p, uint32_t k, uint32_t hq) {
+        const bool same = h_cur == hq;
+        const bool mine = same && lane >= k;
+        c_cur.w = mine ? c_cur.z : c_cur.w; c_cur.z = mine ? c_cur.y : c_cur.z;
+        c_cur.y = mine ? c_cur.x : c_cur.y; c_cur.x = mine ? p : c_cur.x;
+        last_cur = same ? k : last_cur;
+        const bool next = h_nxt == hq;
+        c_nxt.w = next ? c_nxt.z : c_nxt.w; c_nxt.z = next ? c_nxt.y : c_nxt.z;
+        c_nxt.y = next ? c_nxt.x : c_nxt.y; c_nxt.x = next ? p : c_nxt.x;
+    };
+    auto insert_only = [&](uint32_t p) {
+        if (p - q0 >= 64u) { advance(p); q0 = ZFW_UNI(q0); }
+        const uint32_t k = p - q0;
+        enter(p, k, __builtin_amdgcn_readlane(h_cur, k));
+    };
+
+    load_batch(0u, h_cur, c_cur);
+    load_batch(64u, h_nxt, c_nxt);
+    /* deflateSetDictionary inserts every dictionary string; the last two wait for the first input bytes
+     * (deflate.c:364-381, 1471-1489) */
+    for (uint32_t a = 0; a < dict_len && a + ZC_MIN_MATCH <= E; a++) insert_only(a);
+
+    uint32_t B = 0, wend = dict_len, p = dict_len;                    /* fill_window's state, see ZcWindow */
+    uint32_t nsym = 0, blk_sym0 = 0, bstart = dict_len, nblk = 0;     /* _tr_tally's and the block table's, see ZcSink */
+    uint32_t symrow = 0;
+    auto flush = [&](uint32_t last) {                                 /* FLUSH_BLOCK_ONLY, deflate.c:1538-1547 */
+        ZcBlock kb;
+        kb.sym_start = blk_sym0; kb.sym_count = nsym - blk_sym0;
+        kb.in_start = bstart; kb.in_len = p - bstart;
+        kb.flags = (last ? ZC_BF_LAST : 0u) | (bstart >= B ? ZC_BF_CANSTORE : 0u);
+        kb.type = 0; kb.bits = 0; kb.hdr_bits = 0; kb.bit_off = 0;
+        blk(nblk++, kb);
+        blk_sym0 = nsym; bstart = p;
+    };
+    for (;;) {
+        uint32_t look = wend - p;
+        if (look < ZC_MIN_LOOK) {                                     /* fill_window, deflate.c:1390-1494 */
+            if (p - B >= W + (W - ZC_MIN_LOOK)) B += W;
+            const uint64_t cap = (uint64_t)B + 2u * W;
+            wend = E < cap ? E : (uint32_t)cap;
+            look = wend - p;
+            if (look == 0) break;
+        }
+        uint32_t mlen = 0, mdist = 0;
+        if (look >= ZC_MIN_MATCH) {
+            if (p - q0 >= 64u) { advance(p); q0 = ZFW_UNI(q0); }
+            const uint32_t k = p - q0;
+            const uint32_t hq = __builtin_amdgcn_readlane(h_cur, k);
+            const uint32_t s0 = __builtin_amdgcn_readlane(c_cur.x, k), s1 = __builtin_amdgcn_readlane(c_cur.y, k);
+            const uint32_t s2 = __builtin_amdgcn_readlane(c_cur.z, k), s3 = __builtin_amdgcn_readlane(c_cur.w, k);
+            enter(p, k, hq);
+            if (s0 > B && p - s0 <= max_dist) {
+                /* longest_match (deflate.c:1148-1289) with prev_length 2.  The walk goes on while the window index of
+                 * the next string is above the limit (:1158-1159, 1284): the bucket's strings grow older lane by lane,
+                 * so the ones in reach are the first lanes.  Lane k measures candidate k, then the reference's rule
+                 * picks: strictly longer wins, stop at the first one of nice length */
+                const uint32_t lo = p - B > max_dist ? p - max_dist : B;
+                const uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
+                uint32_t thr = nice < look ? nice : look;
+                thr = thr < ZC_MIN_MATCH ? ZC_MIN_MATCH : thr;           /* nothing shorter than 3 beats best_len 2 and ends the walk */
+                uint32_t candv = s3; candv = is2 ? s2 : candv; candv = is1 ? s1 : candv; candv = is0 ? s0 : candv;
+                const bool valid = is0 || (in_ways && candv > lo);
+                uint32_t len = 0;
+                if (valid) {
+                    if (p < wide_end) {
+                        const uint8_t *m = b + candv, *s = b + p;
+                        uint32_t off = 0;
+                        for (;;) {
+                            uint4 a, c;
+                            __builtin_memcpy(&a, m + off, 16); __builtin_memcpy(&c, s + off, 16);
+                            const uint32_t r = zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
+                                                        zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
+                            len = len == off ? off + r : len;          /* a comparison that has ended keeps its length */
+                            off += 16u;
+                            if (off >= cap || __ballot(len == off) == 0ull) break;
+                        }
+                    } else {
+                        const uint8_t *m = b + candv, *s = b + p;
+                        while (len < cap && m[len] == s[len]) len++;
+                    }
+                    len = len < cap ? len : cap;
+                }
+                const unsigned long long gm = __ballot(len >= thr);
+                const uint32_t cut = gm ? (uint32_t)__builtin_ctzll(gm) : 3u;
+                uint32_t key = lane <= cut ? ((len << 2) | inv_lane) : 0u;     /* lanes past the bucket hold length 0 */
+                key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));   /* quad_perm 1,0,3,2 */
+                key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));   /* quad_perm 2,3,0,1 */
+                const uint32_t top = ZFW_UNI(key), best = top >> 2;
+                if (best >= ZC_MIN_MATCH) { mlen = best; mdist = p - __builtin_amdgcn_readlane(candv, 3u - (top & 3u)); }
+            }
+        }
+        uint32_t word;
+        const uint32_t p0 = p;
+        if (mlen >= ZC_MIN_MATCH) {
+            word = zc_sym_match(mlen, mdist);
+            if (mlen <= max_insert && look - mlen >= ZC_MIN_MATCH)
+                for (uint32_t i = 1; i < mlen; i++) insert_only(p0 + i);
+            p = p0 + mlen;
+        } else { word = p0; p = p0 + 1u; }
+        /* _tr_tally (trees.c:1010-1050): symbols leave in rows of 64, lane i & 63 keeps symbol i until the row is full */
+        symrow = lane == (nsym & 63u) ? word : symrow;
+        if ((nsym & 63u) == 63u) symout[(nsym & ~63u) + lane] = symrow;
+        nsym++;
+        if (nsym - blk_sym0 == lim) flush(0);
+    }
+    if (g.final) flush(1);
+    else if (nsym != blk_sym0) flush(0);
+    if (lane < (nsym & 63u)) symout[(nsym & ~63u) + lane] = symrow;    /* the last, partial row */
+    if (lane == 0) {
+        J.nblk[lc] = nblk < J.P.max_blocks ? nblk : J.P.max_blocks;
+        J.nsym[lc] = nsym;
+    }
+}
+#endif
