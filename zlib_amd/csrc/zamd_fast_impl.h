@@ -333,7 +333,9 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
 #define ZFW_UNI(x) __builtin_amdgcn_readfirstlane(x)
 /* position of the lowest set bit, 0xffffffff for 0 (what the instruction returns; __builtin_ctz leaves 0 undefined) */
 __device__ __forceinline__ uint32_t zfw_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
-__device__ __forceinline__ uint32_t zfw_min3(uint32_t a, uint32_t b, uint32_t c) { uint32_t m = a < b ? a : b; return m < c ? m : c; }
+__device__ __forceinline__ uint32_t zfw_min3(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+/* v = wave-uniform x in lane `LANE` (a constant), unchanged elsewhere */
+#define ZFW_SETLANE(v, x, LANE) asm("v_writelane_b32 %0, %1, " #LANE : "+v"(v) : "s"(x))
 /* a wave's own loads see its own earlier stores: order for the compiler, nothing for the hardware to wait for */
 #define ZFW_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
@@ -352,8 +354,10 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
     GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
     /* a comparison may read 16 bytes at a time while 258 + 16 bytes from p on lie inside the buffer */
     const uint32_t wide_end = readable > 274u ? (uint32_t)(readable - 274u < 0xfffffff0ull ? readable - 274u : 0xfffffff0ull) : 0u;
-    const bool is0 = lane == 0, is1 = lane == 1, is2 = lane == 2, in_ways = lane < ways;
-    const uint32_t inv_lane = 3u - lane;
+    /* the last position whose four bytes can be read with one load */
+    const uint32_t quad_end = readable >= 4u ? (uint32_t)(readable - 4u < 0xfffffff0ull ? readable - 4u : 0xfffffff0ull) : 0u;
+    const bool in_ways = lane < ways;
+    const uint32_t inv_lane = 3u - lane, is0 = lane == 0 ? 1u : 0u;
 
     /* ---- the batches: hashes and buckets of positions q0 .. q0 + 127, one position per lane and batch */
     uint32_t q0 = 0, h_cur, h_nxt, last_cur = ZFW_NONE;
@@ -363,8 +367,11 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         const bool ok = a + ZC_MIN_MATCH <= E;
         uint32_t w = 0;
         if (ok) {
-            if ((uint64_t)a + 4u <= readable) __builtin_memcpy(&w, b + a, 4);
-            else for (uint32_t i = 0; i < 4 && (uint64_t)a + i < readable; i++) w |= (uint32_t)b[a + i] << (8u * i);
+            if (readable >= 4u) {                                     /* the three bytes of a string that ends with the buffer come from one byte further down */
+                const uint32_t a4 = a < quad_end ? a : quad_end;
+                __builtin_memcpy(&w, b + a4, 4);
+                w >>= 8u * (a - a4);
+            } else w = (uint32_t)b[a] | ((uint32_t)b[a + 1] << 8) | ((uint32_t)b[a + 2] << 16);
         }
         h = ok ? zc_hash3(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, hshift, hmask) : ZFW_NONE;
         c = make_uint4(0, 0, 0, 0);
@@ -383,6 +390,7 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
             load_batch(q0, h_cur, c_cur);
             load_batch(q0 + 64u, h_nxt, c_nxt);
         }
+        q0 = ZFW_UNI(q0);
     };
     /* INSERT_STRING (deflate.c:186-189): the string at p enters the buckets that later positions of the two batches
      * hold for its hash value, and its own lane's, which becomes the table entry when the batch is left */
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         c_nxt.y = next ? c_nxt.x : c_nxt.y; c_nxt.x = next ? p : c_nxt.x;
     };
     auto insert_only = [&](uint32_t p) {
-        if (p - q0 >= 64u) { advance(p); q0 = ZFW_UNI(q0); }
+        if (p - q0 >= 64u) advance(p);
         const uint32_t k = p - q0;
         enter(p, k, __builtin_amdgcn_readlane(h_cur, k));
     };
@@ -420,47 +428,47 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         blk(nblk++, kb);
         blk_sym0 = nsym; bstart = p;
     };
-    for (;;) {
-        uint32_t look = wend - p;
-        if (look < ZC_MIN_LOOK) {                                     /* fill_window, deflate.c:1390-1494 */
-            if (p - B >= W + (W - ZC_MIN_LOOK)) B += W;
-            const uint64_t cap = (uint64_t)B + 2u * W;
-            wend = E < cap ? E : (uint32_t)cap;
-            look = wend - p;
-            if (look == 0) break;
-        }
+    /* One iteration of deflate_fast's loop (deflate.c:1641-1711) at p with `look` bytes of lookahead.  `full`: the
+     * lookahead is MIN_LOOKAHEAD or more, so no length is cut short by it and every string has its three bytes. */
+    auto step = [&](const bool full, const uint32_t look) {
         uint32_t mlen = 0, mdist = 0;
-        if (look >= ZC_MIN_MATCH) {
-            if (p - q0 >= 64u) { advance(p); q0 = ZFW_UNI(q0); }
+        if (full || look >= ZC_MIN_MATCH) {
+            if (p - q0 >= 64u) advance(p);
             const uint32_t k = p - q0;
             const uint32_t hq = __builtin_amdgcn_readlane(h_cur, k);
             const uint32_t s0 = __builtin_amdgcn_readlane(c_cur.x, k), s1 = __builtin_amdgcn_readlane(c_cur.y, k);
             const uint32_t s2 = __builtin_amdgcn_readlane(c_cur.z, k), s3 = __builtin_amdgcn_readlane(c_cur.w, k);
             enter(p, k, hq);
-            if (s0 > B && p - s0 <= max_dist) {
-                /* longest_match (deflate.c:1148-1289) with prev_length 2.  The walk goes on while the window index of
-                 * the next string is above the limit (:1158-1159, 1284): the bucket's strings grow older lane by lane,
-                 * so the ones in reach are the first lanes.  Lane k measures candidate k, then the reference's rule
-                 * picks: strictly longer wins, stop at the first one of nice length */
-                const uint32_t lo = p - B > max_dist ? p - max_dist : B;
-                const uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
-                uint32_t thr = nice < look ? nice : look;
+            /* longest_match (deflate.c:1148-1289) with prev_length 2.  The head of the chain must not be NIL and at
+             * most MAX_DIST away (:1660); the walk then goes on while the window index of the next string is above
+             * the limit (:1158-1159, 1284): lo is the a-coordinate of that limit.  The bucket's strings grow older
+             * lane by lane, so the ones in reach are the first lanes.  Lane k measures candidate k, then the
+             * reference's rule picks: strictly longer wins, stop at the first one of nice length */
+            const bool far = p - B > max_dist;
+            const uint32_t lo = far ? p - max_dist : B;
+            if (s0 >= (far ? lo : lo + 1u)) {
+                const uint32_t cap = full ? ZC_MAX_MATCH : (look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH);
+                uint32_t thr = full ? (nice < ZC_MIN_LOOK ? nice : ZC_MIN_LOOK) : (nice < look ? nice : look);
                 thr = thr < ZC_MIN_MATCH ? ZC_MIN_MATCH : thr;           /* nothing shorter than 3 beats best_len 2 and ends the walk */
-                uint32_t candv = s3; candv = is2 ? s2 : candv; candv = is1 ? s1 : candv; candv = is0 ? s0 : candv;
-                const bool valid = is0 || (in_ways && candv > lo);
+                uint32_t candv = s0;
+                ZFW_SETLANE(candv, s1, 1); ZFW_SETLANE(candv, s2, 2); ZFW_SETLANE(candv, s3, 3);
+                const bool valid = in_ways & (candv + is0 > lo);         /* lane 0 has passed the head's test */
                 uint32_t len = 0;
                 if (valid) {
                     if (p < wide_end) {
-                        const uint8_t *m = b + candv, *s = b + p;
-                        uint32_t off = 0;
-                        for (;;) {
-                            uint4 a, c;
-                            __builtin_memcpy(&a, m + off, 16); __builtin_memcpy(&c, s + off, 16);
-                            const uint32_t r = zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
-                                                        zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
-                            len = len == off ? off + r : len;          /* a comparison that has ended keeps its length */
-                            off += 16u;
-                            if (off >= cap || __ballot(len == off) == 0ull) break;
+                        uint4 a, c;
+                        __builtin_memcpy(&a, b + candv, 16); __builtin_memcpy(&c, b + p, 16);
+                        len = zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
+                                       zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
+                        if (__ballot(len == 16u) != 0ull) {             /* rare: somebody's first 16 bytes are equal */
+                            uint32_t off = 16u;
+                            do {
+                                __builtin_memcpy(&a, b + (candv + off), 16); __builtin_memcpy(&c, b + (p + off), 16);
+                                const uint32_t r = zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
+                                                            zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
+                                len = len == off ? off + r : len;      /* a comparison that has ended keeps its length */
+                                off += 16u;
+                            } while (off < cap && __ballot(len == off) != 0ull);
                         }
                     } else {
                         const uint8_t *m = b + candv, *s = b + p;
@@ -468,8 +476,7 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
                     }
                     len = len < cap ? len : cap;
                 }
-                const unsigned long long gm = __ballot(len >= thr);
-                const uint32_t cut = gm ? (uint32_t)__builtin_ctzll(gm) : 3u;
+                const uint32_t cut = (uint32_t)__builtin_ctzll(__ballot(len >= thr) | 8ull);
                 uint32_t key = lane <= cut ? ((len << 2) | inv_lane) : 0u;     /* lanes past the bucket hold length 0 */
                 key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));   /* quad_perm 1,0,3,2 */
                 key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));   /* quad_perm 2,3,0,1 */
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         const uint32_t p0 = p;
         if (mlen >= ZC_MIN_MATCH) {
             word = zc_sym_match(mlen, mdist);
-            if (mlen <= max_insert && look - mlen >= ZC_MIN_MATCH)
+            if (mlen <= max_insert && (full || look - mlen >= ZC_MIN_MATCH))
                 for (uint32_t i = 1; i < mlen; i++) insert_only(p0 + i);
             p = p0 + mlen;
         } else { word = p0; p = p0 + 1u; }
@@ -490,6 +497,16 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         if ((nsym & 63u) == 63u) symout[(nsym & ~63u) + lane] = symrow;
         nsym++;
         if (nsym - blk_sym0 == lim) flush(0);
+    };
+    for (;;) {
+        while (wend - p >= ZC_MIN_LOOK) step(true, ZC_MIN_LOOK);
+        /* fill_window, deflate.c:1390-1494 */
+        if (p - B >= W + (W - ZC_MIN_LOOK)) B += W;
+        const uint64_t cap = (uint64_t)B + 2u * W;
+        wend = E < cap ? E : (uint32_t)cap;
+        const uint32_t look = wend - p;
+        if (look == 0) break;
+        if (look < ZC_MIN_LOOK) step(false, look);
     }
     if (g.final) flush(1);
     else if (nsym != blk_sym0) flush(0);
