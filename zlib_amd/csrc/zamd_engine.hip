@@ -1105,6 +1105,7 @@ __global__ __launch_bounds__(1024) void k_ck_fold(const uint32_t *part_a, const 
 
 struct ZeWorkspace {
     uint32_t cap_chunks = 0, chunk_size = 0, max_blocks = 0;
+    bool has_match = false;       /* pdist, rec and hop are allocated (the parsers that search ahead of the parse use them) */
     uint16_t *pdist = nullptr; uint2 *rec = nullptr; uint32_t *sym = nullptr; uint32_t *hop = nullptr; uint32_t *nhop = nullptr;
     ZcBlock *blk = nullptr; ZcBlockTab *tab = nullptr;
     uint32_t *nblk = nullptr, *nsym = nullptr; uint64_t *chunk_bytes = nullptr, *sync_bit = nullptr;
@@ -1158,21 +1159,26 @@ static void ws_free(ZeWorkspace &w)
     w = ZeWorkspace();
 }
 
-static uint64_t ws_bytes_per_chunk(uint32_t chunk_size, uint32_t max_blocks)
+/* with_match: links (2 B), records (8 B) and hop words (4 B) per position, for the parsers that search ahead of the parse */
+static uint64_t ws_bytes_per_chunk(uint32_t chunk_size, uint32_t max_blocks, bool with_match)
 {
-    return 2ull * chunk_size + 8ull * chunk_size + 4ull * chunk_size + 4ull * chunk_size +
+    return (with_match ? 14ull : 0ull) * chunk_size + 4ull * chunk_size +
            (uint64_t)max_blocks * (sizeof(ZcBlock) + sizeof(ZcBlockTab)) + 64;
 }
 
-static int ws_ensure(ZeWorkspace &w, uint32_t chunks, uint32_t chunk_size, uint32_t max_blocks)
+static int ws_ensure(ZeWorkspace &w, uint32_t chunks, uint32_t chunk_size, uint32_t max_blocks, bool with_match)
 {
-    if (w.cap_chunks >= chunks && w.chunk_size == chunk_size && w.max_blocks == max_blocks) return 0;
+    if (w.cap_chunks >= chunks && w.chunk_size == chunk_size && w.max_blocks == max_blocks && (w.has_match || !with_match)) return 0;
+    const bool keep_match = with_match || w.has_match;
     ws_free(w);
-    w.pdist_len = (uint64_t)chunks * chunk_size + ZC_WSIZE + 64;
-    HIPCHK(hipMalloc((void **)&w.pdist, w.pdist_len * 2));
-    HIPCHK(hipMalloc((void **)&w.rec, (uint64_t)chunks * chunk_size * 8));
+    if (keep_match) {
+        w.pdist_len = (uint64_t)chunks * chunk_size + ZC_WSIZE + 64;
+        HIPCHK(hipMalloc((void **)&w.pdist, w.pdist_len * 2));
+        HIPCHK(hipMalloc((void **)&w.rec, (uint64_t)chunks * chunk_size * 8));
+        HIPCHK(hipMalloc((void **)&w.hop, (uint64_t)chunks * chunk_size * 4));
+        w.has_match = true;
+    }
     HIPCHK(hipMalloc((void **)&w.sym, (uint64_t)chunks * chunk_size * 4));
-    HIPCHK(hipMalloc((void **)&w.hop, (uint64_t)chunks * chunk_size * 4));
     HIPCHK(hipMalloc((void **)&w.nhop, (uint64_t)chunks * 4));
     HIPCHK(hipMalloc((void **)&w.blk, (uint64_t)chunks * max_blocks * sizeof(ZcBlock)));
     HIPCHK(hipMalloc((void **)&w.tab, (uint64_t)chunks * max_blocks * sizeof(ZcBlockTab)));
@@ -1386,7 +1392,13 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     HIPCHK(hipSetDevice(e->device));
     const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
     /* batch size from the workspace budget, two batches in flight */
-    uint64_t per = ws_bytes_per_chunk(chunk_size, P.max_blocks);
+    /* levels 1-3 keep their own tables per chunk: a bucket of the newest strings per hash value when the chain budget
+     * fits one (k_fastw), else head[] and prev[] (k_fast) */
+    static const bool fast_links = getenv("ZAMD_FAST_LINKS") != nullptr;
+    const bool fast_ways = P.parser == ZC_PARSE_FAST && P.chain <= ZFW_WAYS && !fast_links;
+    const uint64_t fast_row = P.parser != ZC_PARSE_FAST ? 0ull : fast_ways ? (uint64_t)(P.hash_mask + 1u) * 16u : (uint64_t)ZF_ROW * 2u;
+    const bool with_match = P.parser == ZC_PARSE_SLOW || P.parser == ZC_PARSE_RLE;
+    uint64_t per = ws_bytes_per_chunk(chunk_size, P.max_blocks, with_match) + fast_row;
     const int NS = getenv("ZAMD_SERIAL") ? 1 : e->nstreams;
     uint64_t bc = e->ws_budget / (uint64_t)NS / per;
     if (bc < 1) bc = 1;
@@ -1398,7 +1410,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     if (bc > 0x7fffffu) bc = 0x7fffffu;
     const uint32_t batch = (uint32_t)bc;
     const uint32_t nbatches = (uint32_t)((total_chunks + batch - 1) / batch);
-    for (int i = 0; i < NS && (uint32_t)i < nbatches; i++) { rc = ws_ensure(e->ws[i], batch, chunk_size, P.max_blocks); if (rc) return rc; }
+    for (int i = 0; i < NS && (uint32_t)i < nbatches; i++) { rc = ws_ensure(e->ws[i], batch, chunk_size, P.max_blocks, with_match); if (rc) return rc; }
     uint64_t *d_off = d_chunk_off;
     if (!d_off) {
         if (e->d_off_cap < total_chunks + 1) { hipFree(e->d_off_own); e->d_off_own = nullptr; e->d_off_cap = 0;
@@ -1455,16 +1467,20 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         }
         tm_begin(e, s, 2, &slot);
         if (P.parser == ZC_PARSE_FAST) {
-            /* a chain budget that fits a bucket of the newest strings per hash value needs no links (k_fastw) */
-            static const bool old_fast = getenv("ZAMD_FAST_LINKS") != nullptr;
-            const bool ways = P.chain <= ZFW_WAYS && !old_fast;
-            const uint64_t row = ways ? (uint64_t)(P.hash_mask + 1u) * 16u : (uint64_t)ZF_ROW * 2u;
+            const bool ways = fast_ways;
+            const uint64_t row = fast_row;
             if (w.fhead_bytes < batch * row) {
                 hipFree(w.fhead); w.fhead = nullptr; w.fhead_bytes = 0;
                 HIPCHK(hipMalloc((void **)&w.fhead, batch * row)); w.fhead_bytes = batch * row;
             }
             J.fhead = w.fhead;
             HIPCHK(hipMemsetAsync(w.fhead, 0, J.nchunks * row, s));
+            if (getenv("ZAMD_DEBUG_OCC") && bi == 0) {
+                int nb = 0, nb2 = 0;
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fastw, 64, 0);
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_fast, 64, 0);
+                fprintf(stderr, "zamd: workgroups per CU: k_fastw %d, k_fast %d\n", nb, nb2);
+            }
             if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }

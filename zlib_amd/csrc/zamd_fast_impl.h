@@ -307,7 +307,7 @@ struct ZkFastWCtx {
  * (which stays as the readable form and the fallback of a build with -DZFW_GENERIC), with every piece of the state
  * machine kept wave-uniform in scalar registers. */
 #ifdef ZFW_GENERIC
-__global__ __launch_bounds__(64) void k_fastw(ZkJob J)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fastw(ZkJob J)
 {
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
@@ -359,6 +359,10 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
     const bool in_ways = lane < ways;
     const uint32_t inv_lane = 3u - lane, is0 = lane == 0 ? 1u : 0u;
 
+    const uint32_t pq1 = dict_len + (g.len >> 2), pq2 = dict_len + (g.len >> 1), pq3 = dict_len + (g.len >> 2) * 3u;
+    uint32_t prio_at = pq1;
+    __builtin_amdgcn_s_setprio(3);
+
     /* ---- the batches: hashes and buckets of positions q0 .. q0 + 127, one position per lane and batch */
     uint32_t q0 = 0, h_cur, h_nxt, last_cur = ZFW_NONE;
     uint4 c_cur, c_nxt;
@@ -391,6 +395,14 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
             load_batch(q0 + 64u, h_nxt, c_nxt);
         }
         q0 = ZFW_UNI(q0);
+        /* The instruction arbiter of a SIMD serves its oldest wavefront first, so of the chunks parsed side by side the
+         * ones that started first would finish first and leave the last ones to run with the SIMD half empty.  A
+         * wavefront that is behind asks for more: the priority falls with every quarter of the chunk that is done. */
+        if (p >= prio_at) {
+            if (prio_at == pq1) { __builtin_amdgcn_s_setprio(2); prio_at = pq2; }
+            else if (prio_at == pq2) { __builtin_amdgcn_s_setprio(1); prio_at = pq3; }
+            else { __builtin_amdgcn_s_setprio(0); prio_at = 0xffffffffu; }
+        }
     };
     /* INSERT_STRING (deflate.c:186-189): the string at p enters the buckets that later positions of the two batches
      * hold for its hash value, and its own lane's, which becomes the table entry when the batch is left */
