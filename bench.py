@@ -173,7 +173,7 @@ def main():
 
     # engine workspace: 144 GiB of the 288 GB of HBM (all of the shard's intermediate data resident, four batches
     # in flight at once); the library's own default is 48 GiB
-    ws_gib = int(os.environ.get("ZAMD_BENCH_WS_GIB", "144"))
+    ws_gib = int(os.environ.get("ZAMD_BENCH_WS_GIB", "156"))
     eng = zlib_amd.Engine(local, ws_gib << 30)
     lib = eng.lib
     cpu_model, host_cpus, affinity = host_info()

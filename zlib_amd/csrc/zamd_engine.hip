@@ -1475,12 +1475,6 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             }
             J.fhead = w.fhead;
             HIPCHK(hipMemsetAsync(w.fhead, 0, J.nchunks * row, s));
-            if (getenv("ZAMD_DEBUG_OCC") && bi == 0) {
-                int nb = 0, nb2 = 0;
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fastw, 64, 0);
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, k_fast, 64, 0);
-                fprintf(stderr, "zamd: workgroups per CU: k_fastw %d, k_fast %d\n", nb, nb2);
-            }
             if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
