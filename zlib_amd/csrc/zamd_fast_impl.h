@@ -359,10 +359,6 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
     const bool in_ways = lane < ways;
     const uint32_t inv_lane = 3u - lane, is0 = lane == 0 ? 1u : 0u;
 
-    const uint32_t pq1 = dict_len + (g.len >> 2), pq2 = dict_len + (g.len >> 1), pq3 = dict_len + (g.len >> 2) * 3u;
-    uint32_t prio_at = pq1;
-    __builtin_amdgcn_s_setprio(3);
-
     /* ---- the batches: hashes and buckets of positions q0 .. q0 + 127, one position per lane and batch */
     uint32_t q0 = 0, h_cur, h_nxt, last_cur = ZFW_NONE;
     uint4 c_cur, c_nxt;
@@ -395,14 +391,6 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
             load_batch(q0 + 64u, h_nxt, c_nxt);
         }
         q0 = ZFW_UNI(q0);
-        /* The instruction arbiter of a SIMD serves its oldest wavefront first, so of the chunks parsed side by side the
-         * ones that started first would finish first and leave the last ones to run with the SIMD half empty.  A
-         * wavefront that is behind asks for more: the priority falls with every quarter of the chunk that is done. */
-        if (p >= prio_at) {
-            if (prio_at == pq1) { __builtin_amdgcn_s_setprio(2); prio_at = pq2; }
-            else if (prio_at == pq2) { __builtin_amdgcn_s_setprio(1); prio_at = pq3; }
-            else { __builtin_amdgcn_s_setprio(0); prio_at = 0xffffffffu; }
-        }
     };
     /* INSERT_STRING (deflate.c:186-189): the string at p enters the buckets that later positions of the two batches
      * hold for its hash value, and its own lane's, which becomes the table entry when the batch is left */
@@ -440,61 +428,112 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         blk(nblk++, kb);
         blk_sym0 = nsym; bstart = p;
     };
+    /* ---- searches, sixteen positions at a time.
+     * One comparison of a search is a trip to memory that the parse has to wait for.  A round makes that trip for the
+     * searches of positions r0 .. r0 + 15 together: lane 4 j + w measures candidate w of position r0 + j, from the
+     * bucket that position's lane holds now.  A step at a position of the round whose bucket has not changed since
+     * (no string of its hash value was inserted from r0 on) finds its answer in the round; at level 1 on text three
+     * steps in four do.  Comparisons that run past 16 bytes, positions past the batch and the chunk's last 262 bytes
+     * take the search below, one position at a time. */
+    const uint32_t jl = lane >> 2, way = lane & 3u, inv_way = 3u - way, quad0 = lane & ~3u;
+    const bool way_ok = way < ways, w0 = way == 0, w1 = way == 1, w2 = way == 2;
+    uint32_t r0 = ZFW_NONE, rlen = 0, rkey = 0, rcand = 0;
+    auto lcp16 = [&](uint32_t ca, uint32_t cb) {      /* common prefix of the 16 bytes at a-coordinates ca and cb, in bytes */
+        uint4 a, c;
+        __builtin_memcpy(&a, b + ca, 16); __builtin_memcpy(&c, b + cb, 16);
+        return zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
+                        zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
+    };
+    auto round = [&](uint32_t p, uint32_t k, uint32_t B, uint32_t thr) {
+        const int src = (int)((k + jl) << 2);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)c_cur.x), c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)c_cur.y);
+        const uint32_t c2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)c_cur.z), c3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)c_cur.w);
+        const uint32_t candv = w0 ? c0 : w1 ? c1 : w2 ? c2 : c3;
+        const uint32_t x = p + jl;
+        const bool far = x - B > max_dist;
+        const uint32_t lo = far ? x - max_dist : B;
+        /* the head of the chain may be MAX_DIST away, the strings behind it must be nearer (deflate.c:1660, 1284);
+         * window index 0 is NIL for all of them */
+        const bool ok = way_ok & (k + jl < 64u) & (candv + ((w0 & far) ? 1u : 0u) > lo);
+        uint32_t len = 0;
+        if (ok) len = lcp16(candv, x);
+        const uint32_t mine4 = (uint32_t)(__ballot(len >= thr) >> quad0) & 15u;     /* which of this position's candidates end the walk */
+        const uint32_t cut = zfw_ffbl(mine4 | 8u);
+        uint32_t key = way <= cut ? ((len << 2) | inv_way) : 0u;
+        key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));   /* quad_perm 1,0,3,2 */
+        key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));   /* quad_perm 2,3,0,1 */
+        rkey = key; rcand = candv;
+        r0 = p; rlen = 64u - k < 16u ? 64u - k : 16u;
+    };
+    /* longest_match (deflate.c:1148-1289) with prev_length 2 for the one position p.  The walk goes on while the
+     * window index of the next string is above the limit (:1158-1159, 1284): lo is the a-coordinate of that limit.
+     * The bucket's strings grow older lane by lane, so the ones in reach are the first lanes.  Lane w measures
+     * candidate w, then the reference's rule picks: strictly longer wins, stop at the first one of nice length */
+    auto search = [&](uint32_t p, uint32_t k, uint32_t s0, uint32_t lo, uint32_t cap, uint32_t thr, uint32_t &mlen, uint32_t &mdist) {
+        const uint32_t s1 = __builtin_amdgcn_readlane(c_cur.y, k), s2 = __builtin_amdgcn_readlane(c_cur.z, k), s3 = __builtin_amdgcn_readlane(c_cur.w, k);
+        uint32_t candv = s0;
+        ZFW_SETLANE(candv, s1, 1); ZFW_SETLANE(candv, s2, 2); ZFW_SETLANE(candv, s3, 3);
+        const bool valid = in_ways & (candv + is0 > lo);         /* lane 0 has passed the head's test */
+        uint32_t len = 0;
+        if (valid) {
+            if (p < wide_end) {
+                len = lcp16(candv, p);
+                if (__ballot(len == 16u) != 0ull) {             /* somebody's first 16 bytes are equal */
+                    uint32_t off = 16u;
+                    do {
+                        const uint32_t r = lcp16(candv + off, p + off);
+                        len = len == off ? off + r : len;      /* a comparison that has ended keeps its length */
+                        off += 16u;
+                    } while (off < cap && __ballot(len == off) != 0ull);
+                }
+            } else {
+                const uint8_t *m = b + candv, *sp = b + p;
+#pragma unroll 1
+                while (len < cap && m[len] == sp[len]) len++;
+            }
+            len = len < cap ? len : cap;
+        }
+        const uint32_t cut = (uint32_t)__builtin_ctzll(__ballot(len >= thr) | 8ull);
+        uint32_t key = lane <= cut ? ((len << 2) | inv_lane) : 0u;     /* lanes past the bucket hold length 0 */
+        key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));
+        key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));
+        const uint32_t top = ZFW_UNI(key), best = top >> 2;
+        if (best >= ZC_MIN_MATCH) { mlen = best; mdist = p - __builtin_amdgcn_readlane(candv, 3u - (top & 3u)); }
+    };
+    uint32_t last_step = 1;                           /* how far the last step moved p */
     /* One iteration of deflate_fast's loop (deflate.c:1641-1711) at p with `look` bytes of lookahead.  `full`: the
      * lookahead is MIN_LOOKAHEAD or more, so no length is cut short by it and every string has its three bytes. */
     auto step = [&](const bool full, const uint32_t look) {
         uint32_t mlen = 0, mdist = 0;
         if (full || look >= ZC_MIN_MATCH) {
-            if (p - q0 >= 64u) advance(p);
+            if (p - q0 >= 64u) { advance(p); r0 = ZFW_NONE; }
             const uint32_t k = p - q0;
             const uint32_t hq = __builtin_amdgcn_readlane(h_cur, k);
-            const uint32_t s0 = __builtin_amdgcn_readlane(c_cur.x, k), s1 = __builtin_amdgcn_readlane(c_cur.y, k);
-            const uint32_t s2 = __builtin_amdgcn_readlane(c_cur.z, k), s3 = __builtin_amdgcn_readlane(c_cur.w, k);
-            enter(p, k, hq);
-            /* longest_match (deflate.c:1148-1289) with prev_length 2.  The head of the chain must not be NIL and at
-             * most MAX_DIST away (:1660); the walk then goes on while the window index of the next string is above
-             * the limit (:1158-1159, 1284): lo is the a-coordinate of that limit.  The bucket's strings grow older
-             * lane by lane, so the ones in reach are the first lanes.  Lane k measures candidate k, then the
-             * reference's rule picks: strictly longer wins, stop at the first one of nice length */
+            const uint32_t s0 = __builtin_amdgcn_readlane(c_cur.x, k);
+            /* the head of the chain must not be NIL and at most MAX_DIST away (deflate.c:1660) */
             const bool far = p - B > max_dist;
             const uint32_t lo = far ? p - max_dist : B;
             if (s0 >= (far ? lo : lo + 1u)) {
                 const uint32_t cap = full ? ZC_MAX_MATCH : (look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH);
                 uint32_t thr = full ? (nice < ZC_MIN_LOOK ? nice : ZC_MIN_LOOK) : (nice < look ? nice : look);
                 thr = thr < ZC_MIN_MATCH ? ZC_MIN_MATCH : thr;           /* nothing shorter than 3 beats best_len 2 and ends the walk */
-                uint32_t candv = s0;
-                ZFW_SETLANE(candv, s1, 1); ZFW_SETLANE(candv, s2, 2); ZFW_SETLANE(candv, s3, 3);
-                const bool valid = in_ways & (candv + is0 > lo);         /* lane 0 has passed the head's test */
-                uint32_t len = 0;
-                if (valid) {
-                    if (p < wide_end) {
-                        uint4 a, c;
-                        __builtin_memcpy(&a, b + candv, 16); __builtin_memcpy(&c, b + p, 16);
-                        len = zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
-                                       zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
-                        if (__ballot(len == 16u) != 0ull) {             /* rare: somebody's first 16 bytes are equal */
-                            uint32_t off = 16u;
-                            do {
-                                __builtin_memcpy(&a, b + (candv + off), 16); __builtin_memcpy(&c, b + (p + off), 16);
-                                const uint32_t r = zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
-                                                            zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
-                                len = len == off ? off + r : len;      /* a comparison that has ended keeps its length */
-                                off += 16u;
-                            } while (off < cap && __ballot(len == off) != 0ull);
+                bool served = false;
+                if (full) {
+                    uint32_t j = p - r0;
+                    /* a string inserted since the round began is the newest of its bucket */
+                    bool fresh = j < rlen && s0 < r0;
+                    if (!fresh && last_step < 16u && p + 16u <= wide_end) { round(p, k, B, thr); j = 0; fresh = true; }
+                    if (fresh) {
+                        const uint32_t top = __builtin_amdgcn_readlane(rkey, j << 2), best = top >> 2;
+                        if (best < 16u) {
+                            served = true;
+                            if (best >= ZC_MIN_MATCH) { mlen = best; mdist = p - __builtin_amdgcn_readlane(rcand, (j << 2) + 3u - (top & 3u)); }
                         }
-                    } else {
-                        const uint8_t *m = b + candv, *s = b + p;
-                        while (len < cap && m[len] == s[len]) len++;
                     }
-                    len = len < cap ? len : cap;
                 }
-                const uint32_t cut = (uint32_t)__builtin_ctzll(__ballot(len >= thr) | 8ull);
-                uint32_t key = lane <= cut ? ((len << 2) | inv_lane) : 0u;     /* lanes past the bucket hold length 0 */
-                key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0xB1, 0xf, 0xf, false));   /* quad_perm 1,0,3,2 */
-                key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x4E, 0xf, 0xf, false));   /* quad_perm 2,3,0,1 */
-                const uint32_t top = ZFW_UNI(key), best = top >> 2;
-                if (best >= ZC_MIN_MATCH) { mlen = best; mdist = p - __builtin_amdgcn_readlane(candv, 3u - (top & 3u)); }
+                if (!served) search(p, k, s0, lo, cap, thr, mlen, mdist);
             }
+            enter(p, k, hq);
         }
         uint32_t word;
         const uint32_t p0 = p;
@@ -504,6 +543,7 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
                 for (uint32_t i = 1; i < mlen; i++) insert_only(p0 + i);
             p = p0 + mlen;
         } else { word = p0; p = p0 + 1u; }
+        last_step = p - p0;
         /* _tr_tally (trees.c:1010-1050): symbols leave in rows of 64, lane i & 63 keeps symbol i until the row is full */
         symrow = lane == (nsym & 63u) ? word : symrow;
         if ((nsym & 63u) == 63u) symout[(nsym & ~63u) + lane] = symrow;
@@ -513,7 +553,7 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
     for (;;) {
         while (wend - p >= ZC_MIN_LOOK) step(true, ZC_MIN_LOOK);
         /* fill_window, deflate.c:1390-1494 */
-        if (p - B >= W + (W - ZC_MIN_LOOK)) B += W;
+        if (p - B >= W + (W - ZC_MIN_LOOK)) { B += W; r0 = ZFW_NONE; }          /* a round's limits hold for the window base it saw */
         const uint64_t cap = (uint64_t)B + 2u * W;
         wend = E < cap ? E : (uint32_t)cap;
         const uint32_t look = wend - p;
