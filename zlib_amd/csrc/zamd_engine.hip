@@ -1116,7 +1116,7 @@ struct ZeWorkspace {
 #define ZE_STREAMS 8            /* batches in flight at most */
 struct ZiState;
 struct zamd_engine {
-    int device;
+    int device, cu_count;
     ZiState *inf;                 /* batch-inflate workspace, created on first use */
     hipStream_t st[ZE_STREAMS];
     void (*on_launched)(void *); void *on_launched_arg;   /* called once per deflate call when its last kernel is queued */
@@ -1214,6 +1214,7 @@ extern "C" int zamd_engine_create(zamd_engine **out, int device, uint64_t worksp
     if (const char *v = getenv("ZAMD_STREAMS")) { int k = atoi(v); if (k >= 1 && k <= ZE_STREAMS) e->nstreams = k; }
     e->serialize = getenv("ZAMD_SERIALIZE") ? 1 : 0;
     e->device = device;
+    { hipDeviceProp_t pr; HIPCHK(hipGetDeviceProperties(&pr, device)); e->cu_count = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     e->ws_budget = workspace_bytes ? workspace_bytes : (48ull << 30);
     for (int i = 0; i < ZE_STREAMS; i++) {
         HIPCHK(hipStreamCreateWithFlags(&e->st[i], hipStreamNonBlocking));
@@ -1356,6 +1357,7 @@ static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint
 
 __global__ void k_fast(ZkJob J);
 __global__ void k_fastw(ZkJob J);
+__global__ void k_fastw8(ZkJob J);
 #define ZF_ROW (65536u + 32768u)
 #define ZFW_WAYS 4u
 static void tm_begin(zamd_engine *e, hipStream_t s, int which, int *slot)
@@ -1475,7 +1477,9 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             }
             J.fhead = w.fhead;
             HIPCHK(hipMemsetAsync(w.fhead, 0, J.nchunks * row, s));
-            if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
+            /* all the call's batches are on the GPU together: with more than 24 of their wavefronts to a CU, the build that fits eight to a SIMD */
+            if (ways && total_chunks > 24ull * (uint64_t)e->cu_count) hipLaunchKernelGGL(k_fastw8, dim3(J.nchunks), dim3(64), 0, s, J);
+            else if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
         else if (P.parser == ZC_PARSE_SLOW && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {

@@ -204,132 +204,10 @@ __global__ __launch_bounds__(64) void k_fast(ZkJob J)
 #define ZFW_WAYS 4u
 #endif
 #define ZFW_NONE 0xffffffffu
+#ifndef ZFW_SGPRS
+#define ZFW_SGPRS 64
+#endif
 
-struct ZkFastWCtx {
-    const uint8_t *b; uint64_t readable; uint32_t E;
-    uint4 *tab;                   /* global: one bucket per hash value: a-coordinates of its newest strings, newest first, 0 = none */
-    uint32_t hshift, hmask, nice, chain, lane, max_dist;
-    uint32_t q0;                  /* first position of the current batch */
-    uint32_t h_cur, h_nxt;        /* per lane: hash of q0 + lane, of q0 + 64 + lane (ZFW_NONE: no string starts there) */
-    uint4 c_cur, c_nxt;           /* per lane: the bucket of that hash as the string at that position will find it */
-    uint32_t last_cur;            /* per lane: the lane of the current batch that inserted last under this lane's hash */
-    uint32_t s0, s1, s2, s3;      /* wave-uniform: the bucket the last insertion found */
-
-    __device__ __forceinline__ uint32_t bytes4(uint32_t a) const
-    {
-        uint32_t w = 0;
-        if ((uint64_t)a + 4u <= readable) __builtin_memcpy(&w, b + a, 4);
-        else for (uint32_t i = 0; i < 4 && (uint64_t)a + i < readable; i++) w |= (uint32_t)b[a + i] << (8u * i);
-        return w;
-    }
-    __device__ __forceinline__ void load_batch(uint32_t qb, uint32_t &h, uint4 &c)
-    {
-        const uint32_t a = qb + lane;
-        const bool ok = a + ZC_MIN_MATCH <= E;
-        const uint32_t w = ok ? bytes4(a) : 0u;
-        h = ok ? zc_hash3(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, hshift, hmask) : ZFW_NONE;
-        c = make_uint4(0, 0, 0, 0);
-        if (ok) c = tab[h];
-    }
-    /* the current batch's insertions go to the table */
-    __device__ __forceinline__ void flush_cur()
-    {
-        if (last_cur == lane) tab[h_cur] = c_cur;
-        last_cur = ZFW_NONE;
-        __threadfence_block();
-    }
-    __device__ __forceinline__ void start_batches(uint32_t q)
-    {
-        q0 = q;
-        load_batch(q0, h_cur, c_cur);
-        load_batch(q0 + 64u, h_nxt, c_nxt);
-    }
-    __device__ __forceinline__ uint32_t insert(uint32_t p, uint32_t B)
-    {
-        if (p - q0 >= 64u) {
-            flush_cur();
-            if (p - q0 < 128u) {
-                h_cur = h_nxt; c_cur = c_nxt; q0 += 64u;
-                load_batch(q0 + 64u, h_nxt, c_nxt);
-            } else start_batches(p);
-        }
-        const uint32_t k = p - q0;
-        const uint32_t hq = __builtin_amdgcn_readlane(h_cur, k);
-        s0 = __builtin_amdgcn_readlane(c_cur.x, k); s1 = __builtin_amdgcn_readlane(c_cur.y, k);
-        s2 = __builtin_amdgcn_readlane(c_cur.z, k); s3 = __builtin_amdgcn_readlane(c_cur.w, k);
-        const bool same = h_cur == hq;
-        if (same && lane >= k) c_cur = make_uint4(p, c_cur.x, c_cur.y, c_cur.z);
-        last_cur = same ? k : last_cur;
-        if (h_nxt == hq) c_nxt = make_uint4(p, c_nxt.x, c_nxt.y, c_nxt.z);
-        return s0 > B ? s0 - B : 0u;
-    }
-    __device__ __forceinline__ void slide() {}
-    /* longest_match (deflate.c:1148-1289) with prev_length 2 over the bucket insert() found: lane k measures
-     * candidate k, then the reference's rule picks: strictly longer wins, stop at the first one of nice length. */
-    __device__ __forceinline__ void longest(uint32_t p, uint32_t B, uint32_t, uint32_t look, uint32_t *mlen, uint32_t *mdist)
-    {
-        /* the walk goes on while the window index of the next string is above the limit (deflate.c:1158-1159, 1284) */
-        const uint32_t lo = p - B > max_dist ? p - max_dist : B;
-        const uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH, nice_eff = nice < look ? nice : look;
-        const uint32_t candv = lane == 0 ? s0 : lane == 1 ? s1 : lane == 2 ? s2 : s3;
-        const bool valid = lane == 0 || (lane < ZFW_WAYS && lane < chain && candv > lo);
-        const uint32_t n = (uint32_t)__builtin_ctzll(~__ballot(valid));
-        uint32_t len = 0;
-        if (lane < n) {
-            const uint8_t *m = b + candv, *s = b + p;
-            const bool wide = (uint64_t)p + cap + 16u <= readable;      /* candidates lie below p */
-            while (len < cap) {
-                if (wide) {
-                    uint64_t a0, a1, c0, c1;
-                    __builtin_memcpy(&a0, m + len, 8); __builtin_memcpy(&a1, m + len + 8, 8);
-                    __builtin_memcpy(&c0, s + len, 8); __builtin_memcpy(&c1, s + len + 8, 8);
-                    const uint64_t x0 = a0 ^ c0, x1 = a1 ^ c1;
-                    if (x0) { len += (uint32_t)__builtin_ctzll(x0) >> 3; break; }
-                    if (x1) { len += 8u + ((uint32_t)__builtin_ctzll(x1) >> 3); break; }
-                    len += 16;
-                } else {
-                    if (m[len] != s[len]) break;
-                    len++;
-                }
-            }
-            if (len > cap) len = cap;
-        }
-        uint32_t best = 2, bk = 0;
-        for (uint32_t k = 0; k < n; k++) {
-            const uint32_t l = __builtin_amdgcn_readlane(len, k);
-            if (l > best) { best = l; bk = k; if (best >= nice_eff) break; }
-        }
-        if (best >= ZC_MIN_MATCH) { *mlen = best; *mdist = p - __builtin_amdgcn_readlane(candv, bk); }
-    }
-};
-
-/* deflate_fast (deflate.c:1628-1722) written out for this table; the same steps as zc_parse_fast over ZkFastWCtx
- * (which stays as the readable form and the fallback of a build with -DZFW_GENERIC), with every piece of the state
- * machine kept wave-uniform in scalar registers. */
-#ifdef ZFW_GENERIC
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fastw(ZkJob J)
-{
-    const uint32_t lc = blockIdx.x, lane = threadIdx.x;
-    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
-    ZkFastWCtx cx;
-    cx.b = J.in + g.dstart; cx.readable = J.n - g.dstart; cx.E = g.dict_len + g.len;
-    cx.tab = (uint4 *)J.fhead + (uint64_t)lc * (J.P.hash_mask + 1u);
-    cx.hshift = J.P.hash_shift; cx.hmask = J.P.hash_mask;
-    cx.nice = J.P.nice; cx.chain = J.P.chain; cx.lane = lane; cx.max_dist = J.P.max_dist;
-    cx.last_cur = ZFW_NONE; cx.s0 = cx.s1 = cx.s2 = cx.s3 = 0;
-    cx.start_batches(0);
-    uint32_t symrow = 0;
-    GSymRow sym; sym.s = J.sym + (uint64_t)lc * J.P.chunk_size; sym.lane = lane; sym.row = &symrow;
-    GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
-    uint32_t nsym = 0;
-    const uint32_t nb = zc_parse_fast(g.dict_len, g.len, g.final, J.P, cx, sym, blk, &nsym);
-    if (lane < (nsym & 63u)) sym.s[(nsym & ~63u) + lane] = symrow;          /* the last, partial row */
-    if (lane == 0) {
-        J.nblk[lc] = nb < J.P.max_blocks ? nb : J.P.max_blocks;
-        J.nsym[lc] = nsym;
-    }
-}
-#else
 #define ZFW_UNI(x) __builtin_amdgcn_readfirstlane(x)
 /* position of the lowest set bit, 0xffffffff for 0 (what the instruction returns; __builtin_ctz leaves 0 undefined) */
 __device__ __forceinline__ uint32_t zfw_ffbl(uint32_t x) { uint32_t r; asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
@@ -339,7 +217,7 @@ __device__ __forceinline__ uint32_t zfw_min3(uint32_t a, uint32_t b, uint32_t c)
 /* a wave's own loads see its own earlier stores: order for the compiler, nothing for the hardware to wait for */
 #define ZFW_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront")
 
-__global__ __launch_bounds__(64) void k_fastw(ZkJob J)
+__device__ __forceinline__ void zfw_chunk(const ZkJob &J)
 {
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
@@ -568,4 +446,12 @@ __global__ __launch_bounds__(64) void k_fastw(ZkJob J)
         J.nsym[lc] = nsym;
     }
 }
-#endif
+/* Two builds of the same parser.  A SIMD holds eight wavefronts only if each takes at most 64 scalar registers (a
+ * wavefront's allocation is its count plus 32, in steps of 16, out of 800; measured: 106 registers leave room for
+ * six, 78 for seven); the compiler then keeps part of the state machine in lanes of a vector register, which costs
+ * instructions.  With more chunks in flight than 24 per CU the eighth wavefront is worth it (8 GiB of text at
+ * level 1: 22.4 -> 24.8 GB/s, the last 1 024 chunks no longer start when the first ones are done); with fewer, the
+ * leaner code is (4 GiB: 16.9 against 15.3 GB/s). */
+__global__ __launch_bounds__(64) void k_fastw(ZkJob J) { zfw_chunk(J); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(ZFW_SGPRS))) void k_fastw8(ZkJob J) { zfw_chunk(J); }
+
