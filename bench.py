@@ -171,7 +171,7 @@ def main():
     n = nchunks * CHUNK
     total_chunks = nchunks * world
 
-    # engine workspace: 144 GiB of the 288 GB of HBM (all of the shard's intermediate data resident, four batches
+    # engine workspace: 156 GiB of the 288 GB of HBM (all of the shard's intermediate data resident, four batches
     # in flight at once); the library's own default is 48 GiB
     ws_gib = int(os.environ.get("ZAMD_BENCH_WS_GIB", "156"))
     eng = zlib_amd.Engine(local, ws_gib << 30)
@@ -247,7 +247,7 @@ def main():
     names = ["chain", "match", "parse", "plan", "layout", "emit", "call"]
     kt = {nm: eng.timing_ms(i) for i, nm in enumerate(names)}
     dominant = "match" if kt["match"][1] else "parse"     # levels 1-3 have no separate match kernel
-    kernel_name = "k_match" if dominant == "match" else "k_fast"
+    kernel_name = "k_match" if dominant == "match" else ("k_fastw" if level == 1 else "k_fast")
     roofline = None
     kt_serial = None
     if not args.no_serial_pass:
