@@ -185,7 +185,8 @@ def test_shard_entry_point_with_a_short_head_dictionary(engine, head):
 
 
 @pytest.mark.parametrize("level,tune", [(6, (4, 4, 16, 8)), (6, (8, 258, 258, 300)), (9, (32, 16, 100, 2000)), (4, (1, 0, 3, 1)),
-                                        (5, (40, 300, 1000, 17)), (1, (4, 8, 32, 64)), (2, (4, 3, 9, 1)), (3, (4, 258, 258, 40))])
+                                        (5, (40, 300, 1000, 17)), (1, (4, 8, 32, 64)), (2, (4, 3, 9, 1)), (3, (4, 258, 258, 40)),
+                                        (1, (2, 4, 8, 16)), (3, (1, 6, 32, 32)), (1, (4, 258, 5, 3))])
 def test_tuned_parameters_match_the_oracle(engine, level, tune):
     """deflateTune values instead of the level's table (deflate.c:531-547)."""
     data = O.corpus(3 * 65536 + 1234, 4, 61) + O.corpus(100000, 0, 62)

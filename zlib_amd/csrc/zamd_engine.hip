@@ -1384,6 +1384,9 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     e->pend_bits = 0; e->pend_val = 0; e->data_type = 2;
     if (e->tuned && level != 0) {
         P.good = e->tune[0]; P.lazy = e->tune[1]; P.nice = e->tune[2]; P.chain = e->tune[3];
+        /* deflate_fast always searches with prev_length 2, so a good_length of 2 or less quarters every walk's budget
+         * (deflate.c:1185-1187); a budget of zero wraps in the reference and is as good as unbounded */
+        if (P.parser == ZC_PARSE_FAST && P.good <= ZC_MIN_MATCH - 1) { P.chain >>= 2; if (P.chain == 0) return ZAMD_STREAM_ERROR; }
         /* levels 1-3 compare the candidates of a walk one per lane */
         if (P.parser == ZC_PARSE_FAST && P.chain > 64) return ZAMD_STREAM_ERROR;
     }
