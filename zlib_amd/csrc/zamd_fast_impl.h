@@ -237,9 +237,9 @@ __device__ __forceinline__ void zfw_chunk(const ZkJob &J)
     const bool in_ways = lane < ways;
     const uint32_t inv_lane = 3u - lane, is0 = lane == 0 ? 1u : 0u;
 
-    /* ---- the batches: hashes and buckets of positions q0 .. q0 + 127, one position per lane and batch */
-    uint32_t q0 = 0, h_cur, h_nxt, last_cur = ZFW_NONE;
-    uint4 c_cur, c_nxt;
+    /* ---- the batch: hashes and buckets of positions q0 .. q0 + 63, one position per lane */
+    uint32_t q0 = 0, h_cur, last_cur = ZFW_NONE;
+    uint4 c_cur;
     auto load_batch = [&](uint32_t qb, uint32_t &h, uint4 &c) {
         const uint32_t a = qb + lane;
         const bool ok = a + ZC_MIN_MATCH <= E;
@@ -255,22 +255,17 @@ __device__ __forceinline__ void zfw_chunk(const ZkJob &J)
         c = make_uint4(0, 0, 0, 0);
         if (ok) c = tab[h];
     };
-    /* p has left the current batch: its insertions go to the table, the next batch takes its place */
+    /* p has left the current batch: its insertions go to the table, and the 64 positions from p on are the next batch.
+     * (Gathering a batch further ahead buys nothing: an insertion has to be shifted into every gathered bucket of its
+     * hash value at once, so the gathered data is needed at the next insertion anyway.) */
     auto advance = [&](uint32_t p) {
         if (last_cur == lane) tab[h_cur] = c_cur;
         last_cur = ZFW_NONE;
         ZFW_WAVE_FENCE();
-        if (p - q0 < 128u) {
-            h_cur = h_nxt; c_cur = c_nxt; q0 += 64u;
-            load_batch(q0 + 64u, h_nxt, c_nxt);
-        } else {
-            q0 = p;
-            load_batch(q0, h_cur, c_cur);
-            load_batch(q0 + 64u, h_nxt, c_nxt);
-        }
-        q0 = ZFW_UNI(q0);
+        q0 = p;
+        load_batch(q0, h_cur, c_cur);
     };
-    /* INSERT_STRING (deflate.c:186-189): the string at p enters the buckets that later positions of the two batches
+    /* INSERT_STRING (deflate.c:186-189): the string at p enters the buckets that later positions of the batch
      * hold for its hash value, and its own lane's, which becomes the table entry when the batch is left */
     auto enter = [&](uint32_t p, uint32_t k, uint32_t hq) {
         const bool same = h_cur == hq;
@@ -278,9 +273,6 @@ __device__ __forceinline__ void zfw_chunk(const ZkJob &J)
         c_cur.w = mine ? c_cur.z : c_cur.w; c_cur.z = mine ? c_cur.y : c_cur.z;
         c_cur.y = mine ? c_cur.x : c_cur.y; c_cur.x = mine ? p : c_cur.x;
         last_cur = same ? k : last_cur;
-        const bool next = h_nxt == hq;
-        c_nxt.w = next ? c_nxt.z : c_nxt.w; c_nxt.z = next ? c_nxt.y : c_nxt.z;
-        c_nxt.y = next ? c_nxt.x : c_nxt.y; c_nxt.x = next ? p : c_nxt.x;
     };
     auto insert_only = [&](uint32_t p) {
         if (p - q0 >= 64u) advance(p);
@@ -289,7 +281,6 @@ __device__ __forceinline__ void zfw_chunk(const ZkJob &J)
     };
 
     load_batch(0u, h_cur, c_cur);
-    load_batch(64u, h_nxt, c_nxt);
     /* deflateSetDictionary inserts every dictionary string; the last two wait for the first input bytes
      * (deflate.c:364-381, 1471-1489) */
     for (uint32_t a = 0; a < dict_len && a + ZC_MIN_MATCH <= E; a++) insert_only(a);
