@@ -657,10 +657,11 @@ ZC_HD uint32_t zc_parse_huff(uint32_t dict_len, uint32_t len, uint32_t final_, c
 template <int N>
 struct ZcTree {
     enum { HEAP = 2 * N + 1 };
-    uint32_t pq[HEAP + 1];         /* the priority queue of build_tree: freq << 16 | depth << 10 | node (see zc_build_tree) */
-    uint16_t freq[HEAP];
+    uint32_t pq[HEAP + 1];         /* from the bottom: the priority queue of build_tree, freq << 16 | depth << 10 | node (see
+                                    * zc_build_tree); from the top: the nodes in the order they left the queue, read by gen_bitlen —
+                                    * one array for both, as in the reference (heap[] and heap_max, trees.c:664, 682) */
+    uint16_t freq[N];              /* of the leaves; an inner node's frequency lives in its queue word only */
     uint16_t dad[HEAP];
-    uint16_t heap[HEAP];           /* the nodes in the order they left the queue (trees.c:664, 682), read by gen_bitlen */
     uint8_t  len[HEAP + 3];
     uint16_t bl_count[16];
     int32_t  max_code;
@@ -714,25 +715,24 @@ ZC_HD void zc_build_tree(ZcTree<N> &t, int max_length, bool has_static, StLen st
         t.pq[1] = t.pq[heap_len--]; zc_sift(t, heap_len, 1);
         const uint32_t em = t.pq[1];
         n = (int)(en & 1023u); m = (int)(em & 1023u);
-        t.heap[--heap_max] = (uint16_t)n; t.heap[--heap_max] = (uint16_t)m;
+        t.pq[--heap_max] = (uint32_t)n; t.pq[--heap_max] = (uint32_t)m;      /* the queue has shrunk below heap_max: heap_len + 2 (iterations so far) < HEAP */
         const uint32_t f = (en >> 16) + (em >> 16);
         const uint32_t dn = (en >> 10) & 63u, dm = (em >> 10) & 63u;
         uint32_t d = (dn >= dm ? dn : dm) + 1u;
         if (d > 63u) { d = 63u; t.deep = 1; }
-        t.freq[node] = (uint16_t)f;
         t.dad[n] = t.dad[m] = (uint16_t)node;
         t.pq[1] = (f << 16) | (d << 10) | (uint32_t)node;
         node++;
         zc_sift(t, heap_len, 1);
     } while (heap_len >= 2);
-    t.heap[--heap_max] = (uint16_t)(t.pq[1] & 1023u);
+    { const uint32_t root = t.pq[1] & 1023u; t.pq[--heap_max] = root; }
 
     /* gen_bitlen */
     int h, bits, overflow = 0;
     for (bits = 0; bits <= 15; bits++) t.bl_count[bits] = 0;
-    t.len[t.heap[heap_max]] = 0;
+    t.len[t.pq[heap_max]] = 0;
     for (h = heap_max + 1; h < HEAP; h++) {
-        n = t.heap[h];
+        n = (int)t.pq[h];
         bits = t.len[t.dad[n]] + 1;
         if (bits > max_length) { bits = max_length; overflow++; }
         t.len[n] = (uint8_t)bits;
@@ -752,7 +752,7 @@ ZC_HD void zc_build_tree(ZcTree<N> &t, int max_length, bool has_static, StLen st
     for (bits = max_length; bits != 0; bits--) {
         n = t.bl_count[bits];
         while (n != 0) {
-            m = t.heap[--h];
+            m = (int)t.pq[--h];
             if (m > max_code) continue;
             if ((int)t.len[m] != bits) {
                 *opt_len += (uint32_t)((bits - (int)t.len[m]) * (int)t.freq[m]);

@@ -743,8 +743,8 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
     __shared__ ZcTree<ZC_L_CODES> lt;
     __shared__ ZcTree<ZC_D_CODES> dt;
     __shared__ ZcTree<ZC_BL_CODES> bt;
-    __shared__ uint32_t hist[288 + 32];
     __shared__ uint32_t cost[4];
+    uint32_t *const hist = lt.pq;                 /* 288 + 32 counters; the queue takes the array over once the counts are in freq[] */
     const uint32_t tid = threadIdx.x;
     const uint32_t lc = blockIdx.y, j = blockIdx.x;
     if (j >= J.nblk[lc]) return;
