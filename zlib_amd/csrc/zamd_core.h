@@ -775,18 +775,19 @@ ZC_HD void zc_assign_codes(const ZcTree<N> &t, Tab &tab, int count)
     }
 }
 
-/* LSB-first bit writer into a byte array that starts zeroed (send_bits, trees.c:213). */
+/* LSB-first bit writer (send_bits, trees.c:213) into 32-bit words, little endian: bits gather in a register and leave a
+ * word at a time, so the buffer is only ever written (and need not start zeroed); flush() writes the last, partial word
+ * with zeros above its bits.  v holds nothing above its n bits. */
 struct ZcBitW {
-    uint8_t *buf; uint32_t nbits;
+    uint32_t *buf; uint32_t nbits;
+    uint64_t acc; uint32_t fill, widx;
+    ZC_HD void begin(void *words) { buf = (uint32_t *)words; nbits = 0; acc = 0; fill = 0; widx = 0; }
     ZC_HD void put(uint32_t v, uint32_t n)
     {
-        uint32_t pos = nbits; nbits += n;
-        while (n) {
-            uint32_t sh = pos & 7u, room = 8u - sh, take = n < room ? n : room;
-            buf[pos >> 3] = (uint8_t)(buf[pos >> 3] | ((v & ((1u << take) - 1u)) << sh));
-            v >>= take; n -= take; pos += take;
-        }
+        acc |= (uint64_t)v << fill; fill += n; nbits += n;
+        if (fill >= 32u) { buf[widx++] = (uint32_t)acc; acc >>= 32; fill -= 32u; }
     }
+    ZC_HD void flush() { if (fill) buf[widx] = (uint32_t)acc; }
 };
 
 /* scan_tree / send_tree (trees.c:705-795).  With w == nullptr counts the
@@ -829,7 +830,7 @@ ZC_HD void zc_walk_lengths(Len len, int max_code, uint16_t *blfreq, const uint32
 struct ZcBlockTab {
     uint32_t lc[288];        /* code | len<<16 */
     uint32_t dc[32];
-    uint8_t  hdr[ZC_HDR_BYTES];
+    uint8_t  hdr[ZC_HDR_BYTES];   /* the tree description (send_all_trees) as little-endian 32-bit words; bits past hdr_bits are not defined */
 };
 
 /* The serial tail of _tr_flush_block() (trees.c:938-989) once the literal and
@@ -865,8 +866,7 @@ ZC_HD void zc_plan_block(ZcTree<ZC_L_CODES> &lt, ZcTree<ZC_D_CODES> &dt, ZcTree<
         zc_assign_codes(dt, tab->dc, 32);
         uint32_t bltab[ZC_BL_CODES];
         zc_assign_codes(bt, bltab, ZC_BL_CODES);
-        for (int i = 0; i < ZC_HDR_BYTES; i++) tab->hdr[i] = 0;
-        ZcBitW w; w.buf = tab->hdr; w.nbits = 0;
+        ZcBitW w; w.begin(tab->hdr);
         /* send_all_trees, trees.c:836-860 */
         w.put((uint32_t)(lt.max_code + 1 - 257), 5);
         w.put((uint32_t)(dt.max_code + 1 - 1), 5);
@@ -874,6 +874,7 @@ ZC_HD void zc_plan_block(ZcTree<ZC_L_CODES> &lt, ZcTree<ZC_D_CODES> &dt, ZcTree<
         for (int r = 0; r <= max_bl; r++) w.put(bt.len[bl_order[r]], 3);
         zc_walk_lengths([&](int n) { return lt.len[n]; }, lt.max_code, nullptr, bltab, &w);
         zc_walk_lengths([&](int n) { return dt.len[n]; }, dt.max_code, nullptr, bltab, &w);
+        w.flush();
         b->hdr_bits = w.nbits;
     }
 }
