@@ -505,35 +505,42 @@ struct GRec2 {
     __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q) const { uint2 v = r[p - dict_len]; *f = v.x; *q = v.y; }
 };
 
-__global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t tiles_per_chunk)
+/* A workgroup takes ZK_RESOLVE_SPAN tiles of its chunk in a row: the chunk's geometry (64-bit arithmetic, the same for
+ * every thread) costs more than one position's hop word, so it is worked out once for 8 192 positions, not for 1 024. */
+#define ZK_RESOLVE_SPAN 8u
+__global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t spans_per_chunk)
 {
     __shared__ unsigned long long s_mask[ZK_RESOLVE_TILE / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
+    const uint32_t lc = blockIdx.x / spans_per_chunk, span = blockIdx.x % spans_per_chunk;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
-    const uint32_t i0 = tile * ZK_RESOLVE_TILE;
-    if (i0 >= g.len) return;
-    const uint32_t tl = g.len - i0 < ZK_RESOLVE_TILE ? g.len - i0 : ZK_RESOLVE_TILE;
     const uint32_t E = g.dict_len + g.len;
     GRec2 rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
-    uint32_t h = 0;
-    if (tid < tl) h = zc_resolve_pos(rec, g.dict_len + i0 + tid, E, J.P);
-    unsigned long long m = __ballot((h & ZC_HOP_MATCH) != 0);
-    if (lane == 0) s_mask[wv] = m;
-    __syncthreads();
-    if (tid < tl && !(h & ZC_HOP_MATCH)) {
-        /* literal: distance to the next position of the tile where a match starts (or to the tile's end) */
-        unsigned long long mm = m & (~0ull << lane);
-        uint32_t next = tl;
-        if (mm) next = wv * 64u + (uint32_t)__ffsll((long long)mm) - 1u;
-        else for (uint32_t w = wv + 1; w < ZK_RESOLVE_TILE / 64; w++) {
-            unsigned long long x = s_mask[w];
-            if (x) { next = w * 64u + (uint32_t)__ffsll((long long)x) - 1u; break; }
+    uint32_t *const hop = J.hop + (uint64_t)lc * J.P.chunk_size;
+    for (uint32_t t = 0; t < ZK_RESOLVE_SPAN; t++) {
+        const uint32_t i0 = (span * ZK_RESOLVE_SPAN + t) * ZK_RESOLVE_TILE;
+        if (i0 >= g.len) return;
+        const uint32_t tl = g.len - i0 < ZK_RESOLVE_TILE ? g.len - i0 : ZK_RESOLVE_TILE;
+        uint32_t h = 0;
+        if (tid < tl) h = zc_resolve_pos(rec, g.dict_len + i0 + tid, E, J.P);
+        unsigned long long m = __ballot((h & ZC_HOP_MATCH) != 0);
+        if (lane == 0) s_mask[wv] = m;
+        __syncthreads();
+        if (tid < tl && !(h & ZC_HOP_MATCH)) {
+            /* literal: distance to the next position of the tile where a match starts (or to the tile's end) */
+            unsigned long long mm = m & (~0ull << lane);
+            uint32_t next = tl;
+            if (mm) next = wv * 64u + (uint32_t)__ffsll((long long)mm) - 1u;
+            else for (uint32_t w = wv + 1; w < ZK_RESOLVE_TILE / 64; w++) {
+                unsigned long long x = s_mask[w];
+                if (x) { next = w * 64u + (uint32_t)__ffsll((long long)x) - 1u; break; }
+            }
+            if (next > tl) next = tl;
+            h = next - tid;
         }
-        if (next > tl) next = tl;
-        h = next - tid;
+        if (tid < tl) hop[i0 + tid] = h;
+        __syncthreads();                       /* the masks are read before the next tile writes them */
     }
-    if (tid < tl) J.hop[(uint64_t)lc * J.P.chunk_size + i0 + tid] = h;
 }
 
 #define ZK_HOP_TILE 512u
@@ -1486,7 +1493,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
         else if (P.parser == ZC_PARSE_SLOW && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {
-            const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE - 1) / ZK_RESOLVE_TILE;
+            const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE * ZK_RESOLVE_SPAN - 1) / (ZK_RESOLVE_TILE * ZK_RESOLVE_SPAN);
             if (dense) hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
             if (dense) hipLaunchKernelGGL(k_hopw, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_hop<true>, dim3(J.nchunks), dim3(64), 0, s, J);
