@@ -541,7 +541,10 @@ int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int mem
     uint64_t chunk = env_u64("ZAMD_Z_CHUNK", 1u << 20);
     if (chunk < 32768 || chunk > (64u << 20) || (chunk & 16383)) chunk = 1u << 20;
     s->chunk_size = (uint32_t)chunk;
-    uint64_t batch = env_u64("ZAMD_Z_BATCH_MIB", 512) << 20;
+    // deflate_fast is one wavefront per chunk: what it runs at is the number of chunks in one engine call (a 512 MiB batch
+    // of level 1 occupies two wavefront slots of a CU and takes as long as one of 6 GiB), so levels 1-3 take larger batches
+    const bool fast_levels = level >= 1 && level <= 3 && strategy != Z_HUFFMAN_ONLY && strategy != Z_RLE;
+    uint64_t batch = env_u64("ZAMD_Z_BATCH_MIB", fast_levels ? 1024 : 512) << 20;
     if (batch < chunk) batch = chunk;
     s->batch_bytes = batch / chunk * chunk;
     strm->state = (struct internal_state *)s;
@@ -710,6 +713,18 @@ static int deflate_body(z_streamp strm, int flush) {
     // Accept input; compress whenever a full batch is available.  Input is only
     // accepted while the pending output is empty, which bounds host memory.
     bool flushed = false;                  // the flush's own engine call has run inside a row of overlapped batches
+    // Levels 1-3 with everything at hand (compress2, a one-shot deflate(Z_FINISH)): the whole input is one engine call.
+    // Their parser is one wavefront per chunk, so the call takes about as long for 6 000 chunks as for 500, and cutting
+    // the input into batches that overlap their transfers loses more than the overlap gains.
+    if (flush == Z_FINISH && s->status != ST_FINISH && s->level >= 1 && s->level <= 3 && s->strategy != Z_HUFFMAN_ONLY &&
+        s->strategy != Z_RLE && s->in.empty() && s->out.size() == s->out_pos && strm->avail_in > s->batch_bytes &&
+        strm->avail_out >= zamd_deflate_bound(strm->avail_in, s->chunk_size, s->mem_level) + 64) {
+        const uint64_t n = strm->avail_in;
+        int rc = run_batch(strm, s, strm->next_in, n, 1);
+        if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
+        strm->next_in += n; strm->avail_in = 0; strm->total_in += n;
+        flushed = true;
+    }
     while (strm->avail_in != 0) {
         int rc;
         // whole batches that can go straight from the caller's input to the caller's output, overlapped on the GPU
