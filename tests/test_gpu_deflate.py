@@ -239,6 +239,36 @@ def test_parse_driven_matcher_is_exact_too():
     eng.close()
 
 
+def test_level_1_build_for_eight_wavefronts_per_simd_is_exact_too():
+    """k_fastw exists in two builds; the one capped at 64 scalar registers is picked for calls of more than 24 chunks per CU.
+    ZAMD_FASTW8=1 picks it for any call (read once per process, hence the child process)."""
+    import subprocess, sys
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _oracle as O, zlib_amd
+eng = zlib_amd.Engine(0)
+data = O.corpus(5 * 65536 + 4321, 0, 91) + O.corpus(200000, 4, 92) + bytes(40000) + O.corpus(65536, 1, 93)
+for level, strategy, mem, chunk in ((1, 0, 8, 65536), (1, 0, 9, 131072), (1, 4, 1, 65536), (1, 1, 8, 32768)):
+    out, _ = eng.deflate_chunks(data, level=level, strategy=strategy, mem_level=mem, chunk_size=chunk)
+    assert out == O.deflate_chunked(data, chunk, level, strategy, mem)[0], (level, strategy, mem, chunk)
+eng.tune(4, 258, 5, 3)
+out, _ = eng.deflate_chunks(data, level=2, chunk_size=65536)
+want = b""
+nch = (len(data) + 65535) // 65536
+for c in range(nch):
+    start = c * 65536
+    dl, ln = min(start, 32768), min(65536, len(data) - start)
+    want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, 2, 0, 8, c == nch - 1, tune=(4, 258, 5, 3))
+assert out == want
+eng.close()
+print("ok")
+""" % (os.path.join(ROOT, "tests"), ROOT)
+    env = dict(os.environ, ZAMD_FASTW8="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("level,tune", [(6, (4, 64, 8, 128)), (5, (20, 258, 9, 3)), (8, (1, 16, 4, 2)), (6, (33, 1, 8, 2)), (6, (14, 2, 9, 1))])
 def test_tuned_parameters_outside_the_tables_shape(engine, level, tune):
     """nice_length below max_lazy, chain budgets whose quarter is zero, lazy limits below 3."""

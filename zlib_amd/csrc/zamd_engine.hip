@@ -1488,7 +1488,9 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             J.fhead = w.fhead;
             HIPCHK(hipMemsetAsync(w.fhead, 0, J.nchunks * row, s));
             /* all the call's batches are on the GPU together: with more than 24 of their wavefronts to a CU, the build that fits eight to a SIMD */
-            if (ways && total_chunks > 24ull * (uint64_t)e->cu_count) hipLaunchKernelGGL(k_fastw8, dim3(J.nchunks), dim3(64), 0, s, J);
+            static const char *force8 = getenv("ZAMD_FASTW8");      /* tests: "1" = always the eight-wavefront build, "0" = never */
+            const bool eight = force8 ? force8[0] == '1' : total_chunks > 24ull * (uint64_t)e->cu_count;
+            if (ways && eight) hipLaunchKernelGGL(k_fastw8, dim3(J.nchunks), dim3(64), 0, s, J);
             else if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
