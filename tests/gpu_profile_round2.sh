@@ -25,7 +25,12 @@ timeout -k 10 500 python3 bench.py > $O/bench_line.json 2> $O/bench_default.err 
 timeout -k 10 500 python3 bench.py --workload l1_text > $O/bench_l1_text.json 2> $O/bench_l1.err || { tail -5 $O/bench_l1.err; exit 1; }
 timeout -k 10 500 python3 bench.py --workload l9_lowent --chunks-per-gpu 4096 --no-cpu-baseline > $O/bench_l9_lowent.json 2> $O/bench_l9.err || { tail -5 $O/bench_l9.err; exit 1; }
 timeout -k 10 500 python3 bench.py --workload l6_text --no-cpu-baseline > $O/bench_l6_text.json 2> $O/bench_l6t.err || { tail -5 $O/bench_l6t.err; exit 1; }
+timeout -k 10 500 python3 bench.py --workload l1_text --chunks-per-gpu 4096 --no-cpu-baseline > $O/bench_l1_text_4gib.json 2> $O/bench_l1b.err || { tail -5 $O/bench_l1b.err; exit 1; }
+for w in l9_image_filtered l6_lowent_huff l6_image_rle; do
+  timeout -k 10 500 python3 bench.py --workload $w --chunks-per-gpu 4096 --no-cpu-baseline --no-serial-pass > $O/bench_$w.json 2> $O/bench_w.err || { tail -5 $O/bench_w.err; exit 1; }
+done
 # 6. the stream API on host buffers
 timeout -k 10 300 python3 -u tests/gpu_api_bench.py 3584 6 > $O/api_host_buffers.txt 2>&1 || { tail -5 $O/api_host_buffers.txt; exit 1; }
+timeout -k 10 300 python3 -u tests/gpu_api_bench.py 3584 1 > $O/api_host_buffers_l1.txt 2>&1 || { tail -5 $O/api_host_buffers_l1.txt; exit 1; }
 rm -rf $O/prof_serial $O/prof $O/pmc_fetch $O/pmc_write $O/pmc_sqa $O/pmc_sqb
 ls -la $O

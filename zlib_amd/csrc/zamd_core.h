@@ -441,6 +441,12 @@ template <class Rec>
 ZC_HD uint32_t zc_resolve_pos(Rec rec, uint32_t p, uint32_t E, const ZcParams &P)
 {
     uint32_t rf, rq, L, D;
+    if (P.parser == ZC_PARSE_RLE) {                        /* deflate_rle (deflate.c:1861-1928): a run of three or more is taken as it stands */
+        if (E - p < ZC_MIN_MATCH) return 0;
+        rec(p, &rf, &rq);
+        const uint32_t l = rf & 0xffffu;
+        return l >= ZC_MIN_MATCH ? zc_hop_pack(0, l, 1) : 0u;
+    }
     if (E - p < ZC_MIN_MATCH || P.lazy < ZC_MIN_MATCH) return 0;      /* prev_length (2) < max_lazy_match, deflate.c:1765 */
     rec(p, &rf, &rq);
     if (!zc_accept(rf, rq, ZC_MIN_MATCH - 1, P, &L, &D)) return 0;

@@ -664,6 +664,11 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
     const uint32_t lc = blockIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     const uint32_t E = g.dict_len + g.len, lim = J.P.lit_bufsize - 1;
+    /* deflate_slow tallies the symbol that starts at pos in the iteration that stands at pos + 1, refills its window below
+     * MIN_LOOKAHEAD and tallies a pending literal after its loop (deflate.c:1744, 1796-1829, 1840-1844); deflate_rle tallies
+     * it in the iteration at pos, refills at MAX_MATCH or less and has nothing pending (:1874, 1906-1920) */
+    const bool rle = J.P.parser == ZC_PARSE_RLE;
+    const uint32_t top_off = rle ? 0u : 1u, look_thr = rle ? ZC_MAX_MATCH + 1u : ZC_MIN_LOOK;
     const uint32_t H = J.nhop[lc];
     const uint32_t *hop = J.hop + (uint64_t)lc * J.P.chunk_size;
     const uint32_t *arr = J.arr + (uint64_t)lc * (J.P.chunk_size / 2);
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
             sym[sidx] = word;
             if ((sidx + 1) % lim == 0) {
                 uint32_t b = (sidx + 1) / lim - 1;
-                if (b < J.P.max_blocks) { blk[b].bits = endpos; blk[b].hdr_bits = pos + 1; }
+                if (b < J.P.max_blocks) { blk[b].bits = endpos; blk[b].hdr_bits = pos + top_off; }
             }
         }
         base_sym += total;
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
     if ((H % ZK_EXPAND_THREADS) == tid) s_tail = tail_lits;
     __syncthreads();
     const uint32_t nsym = base_sym;
-    uint32_t nb = zc_block_count(nsym, lim, g.final, s_tail != 0);
+    uint32_t nb = zc_block_count(nsym, lim, g.final, !rle && s_tail != 0);
     if (nb > J.P.max_blocks) { if (tid == 0) atomicOr(J.err, (uint32_t)ZE_BLOCK_OVERFLOW); nb = J.P.max_blocks; }
     /* assemble the block table (FLUSH_BLOCK_ONLY, deflate.c:1538-1547) */
     for (uint32_t b0 = 0; b0 < nb; b0 += ZK_EXPAND_THREADS) {
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
             B.sym_start = b * lim; B.sym_count = (b + 1 < nb) ? lim : nsym - b * lim;
             B.in_start = in_start; B.in_len = in_end - in_start;
             B.flags = ((b + 1 == nb && g.final) ? ZC_BF_LAST : 0u) |
-                      (in_start >= zc_window_base(p_top, E, ZC_MIN_LOOK, J.P.wsize) ? ZC_BF_CANSTORE : 0u);
+                      (in_start >= zc_window_base(p_top, E, look_thr, J.P.wsize) ? ZC_BF_CANSTORE : 0u);
             B.type = 0; B.bits = b + 1 == nb ? 0u : in_end; B.hdr_bits = 0; B.bit_off = 0;
             blk[b] = B;
         }
@@ -1494,7 +1499,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             else if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
-        else if (P.parser == ZC_PARSE_SLOW && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {
+        else if ((P.parser == ZC_PARSE_SLOW || P.parser == ZC_PARSE_RLE) && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {
             const uint32_t rtiles = (chunk_size + ZK_RESOLVE_TILE * ZK_RESOLVE_SPAN - 1) / (ZK_RESOLVE_TILE * ZK_RESOLVE_SPAN);
             if (dense) hipLaunchKernelGGL(k_resolve, dim3(J.nchunks * rtiles), dim3(ZK_RESOLVE_TILE), 0, s, J, rtiles);
             if (dense) hipLaunchKernelGGL(k_hopw, dim3(J.nchunks), dim3(64), 0, s, J);
