@@ -33,6 +33,8 @@ WORKLOADS = {
     "l9_lowent": (2, 3, 9, 0, 8),
     "l6_text": (0, 1, 6, 0, 8),
     "l1_text": (0, 1, 1, 0, 8),       # deflate_fast
+    "l2_text": (0, 1, 2, 0, 8),
+    "l3_text": (0, 1, 3, 0, 8),
     # the strategies of BASELINE configs[3] on its corpora
     "l9_image_filtered": (3, 4, 9, 1, 8),
     "l6_lowent_huff": (2, 3, 6, 2, 8),

@@ -1370,6 +1370,8 @@ static int fill_params(ZcParams &P, int level, int strategy, int mem_level, uint
 __global__ void k_fast(ZkJob J);
 __global__ void k_fastw(ZkJob J);
 __global__ void k_fastw8(ZkJob J);
+__global__ void k_fastr(ZkJob J);
+#define ZFR_WAYS 32u
 #define ZF_ROW (65536u + 32768u)
 #define ZFW_WAYS 4u
 static void tm_begin(zamd_engine *e, hipStream_t s, int which, int *slot)
@@ -1413,7 +1415,9 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
      * fits one (k_fastw), else head[] and prev[] (k_fast) */
     static const bool fast_links = getenv("ZAMD_FAST_LINKS") != nullptr;
     const bool fast_ways = P.parser == ZC_PARSE_FAST && P.chain <= ZFW_WAYS && !fast_links;
-    const uint64_t fast_row = P.parser != ZC_PARSE_FAST ? 0ull : fast_ways ? (uint64_t)(P.hash_mask + 1u) * 16u : (uint64_t)ZF_ROW * 2u;
+    const bool fast_ring = P.parser == ZC_PARSE_FAST && !fast_ways && P.chain <= ZFR_WAYS && !fast_links;      /* k_fastr: a ring of 32 strings and a count per hash value */
+    const uint64_t fast_row = P.parser != ZC_PARSE_FAST ? 0ull : fast_ways ? (uint64_t)(P.hash_mask + 1u) * 16u :
+                              fast_ring ? (uint64_t)(P.hash_mask + 1u) * (ZFR_WAYS + 1u) * 4u : (uint64_t)ZF_ROW * 2u;
     const bool with_match = P.parser == ZC_PARSE_SLOW || P.parser == ZC_PARSE_RLE;
     uint64_t per = ws_bytes_per_chunk(chunk_size, P.max_blocks, with_match) + fast_row;
     const int NS = getenv("ZAMD_SERIAL") ? 1 : e->nstreams;
@@ -1497,6 +1501,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             const bool eight = force8 ? force8[0] == '1' : total_chunks > 24ull * (uint64_t)e->cu_count;
             if (ways && eight) hipLaunchKernelGGL(k_fastw8, dim3(J.nchunks), dim3(64), 0, s, J);
             else if (ways) hipLaunchKernelGGL(k_fastw, dim3(J.nchunks), dim3(64), 0, s, J);
+            else if (fast_ring) hipLaunchKernelGGL(k_fastr, dim3(J.nchunks), dim3(64), 0, s, J);
             else hipLaunchKernelGGL(k_fast, dim3(J.nchunks), dim3(64), 0, s, J);
         }
         else if ((P.parser == ZC_PARSE_SLOW || P.parser == ZC_PARSE_RLE) && !(dense && getenv("ZAMD_SERIAL_PARSE"))) {

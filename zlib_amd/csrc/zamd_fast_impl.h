@@ -446,3 +446,214 @@ __device__ __forceinline__ void zfw_chunk(const ZkJob &J)
 __global__ __launch_bounds__(64) void k_fastw(ZkJob J) { zfw_chunk(J); }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(ZFW_SGPRS))) void k_fastw8(ZkJob J) { zfw_chunk(J); }
 
+
+/* ------------------------------------------------------------------ k_fastr
+ * deflate_fast for chain budgets of 5 to 32 (levels 2 and 3).  The same fact as in k_fastw — head[h] and the links
+ * behind it are the strings inserted under hash value h, newest first — with buckets too large for registers: per hash
+ * value a ring of the ZFR_WAYS newest strings (a-coordinates) and a count of all that were ever inserted, in global
+ * memory.  A search reads the whole ring with one load (lane j takes slot j, lane ZFR_WAYS the count), knows every
+ * slot's age from the count, measures all candidates at once and picks by age: no walk along links, of which level 3
+ * made up to 32 dependent trips to memory per search.  An insertion is one store into the ring and one of the count;
+ * the strings inside a short match go in together (their counts gathered with one load, strings of one hash value
+ * ranked among themselves). */
+#ifndef ZFR_WAYS
+#define ZFR_WAYS 32u
+#endif
+
+__global__ __launch_bounds__(64) void k_fastr(ZkJob J)
+{
+    const uint32_t lc = blockIdx.x, lane = threadIdx.x;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
+    const uint8_t *const b = J.in + g.dstart;
+    const uint64_t readable = J.n - g.dstart;
+    const uint32_t dict_len = g.dict_len, E = g.dict_len + g.len;
+    const uint32_t hsize = J.P.hash_mask + 1u;
+    uint32_t *const ring = (uint32_t *)J.fhead + (uint64_t)lc * hsize * (ZFR_WAYS + 1u);
+    uint32_t *const cnt = ring + (uint64_t)hsize * ZFR_WAYS;
+    const uint32_t hshift = J.P.hash_shift, hmask = J.P.hash_mask, nice = J.P.nice, max_dist = J.P.max_dist;
+    const uint32_t chain = J.P.chain < ZFR_WAYS ? J.P.chain : ZFR_WAYS;
+    const uint32_t W = J.P.wsize, max_insert = J.P.lazy, lim = J.P.lit_bufsize - 1u;
+    uint32_t *const symout = J.sym + (uint64_t)lc * J.P.chunk_size;
+    GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
+    /* a comparison may read 16 bytes at a time while 258 + 16 bytes from p on lie inside the buffer */
+    const uint32_t wide_end = readable > 274u ? (uint32_t)(readable - 274u < 0xfffffff0ull ? readable - 274u : 0xfffffff0ull) : 0u;
+
+    /* the 16 bytes from a-coordinate x on (x wave-uniform), zero past the buffer's end */
+    auto load16 = [&](uint32_t x) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if ((uint64_t)x + 16u <= readable) __builtin_memcpy(&v, b + x, 16);
+        else {
+            uint32_t t[4] = {0, 0, 0, 0};
+            for (uint32_t i = 0; i < 16u && (uint64_t)x + i < readable; i++) t[i >> 2] |= (uint32_t)b[x + i] << (8u * (i & 3u));
+            v = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        return v;
+    };
+    /* hash of the string that starts i bytes into v (i per lane, at most 12) */
+    auto hash_at = [&](const uint4 &v, uint32_t i) {
+        const uint32_t d = i >> 2;
+        const uint32_t lo = d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w;
+        const uint32_t hi = d == 0 ? v.y : d == 1 ? v.z : d == 2 ? v.w : 0u;
+        const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, i & 3u);
+        return zc_hash3(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, hshift, hmask);
+    };
+    /* INSERT_STRING (deflate.c:186-189) for the m strings at x0 .. x0 + m - 1, lane i holding the hash of x0 + i: strings of
+     * one hash value take consecutive slots in position order, the last of them leaves the count */
+    auto insert_many = [&](uint32_t x0, uint32_t m, uint32_t h) {
+        const bool act = lane < m;
+        uint32_t c = 0;
+        if (act) c = cnt[h];
+        uint32_t rank = 0, later = 0;
+        for (uint32_t k = 0; k < m; k++) {
+            const uint32_t hk = __builtin_amdgcn_readlane(h, k);
+            const bool same = act && h == hk;
+            rank += (same && lane > k) ? 1u : 0u;
+            later |= (same && lane < k) ? 1u : 0u;
+        }
+        if (act) {
+            ring[(uint64_t)h * ZFR_WAYS + ((c + rank) & (ZFR_WAYS - 1u))] = x0 + lane;
+            if (!later) cnt[h] = c + rank + 1u;
+        }
+        ZFW_WAVE_FENCE();
+    };
+    auto wave_max32 = [&](uint32_t x) {                    /* over lanes 0 .. 31 */
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false));     /* quad_perm 1,0,3,2 */
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false));     /* quad_perm 2,3,0,1 */
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false));    /* row_half_mirror */
+        x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false));    /* row_mirror */
+        const uint32_t a = __builtin_amdgcn_readlane(x, 0), c = __builtin_amdgcn_readlane(x, 16);
+        return a > c ? a : c;
+    };
+    auto lcp16v = [&](uint32_t ca, const uint4 &c) {       /* common prefix of the 16 bytes at a-coordinate ca with c */
+        uint4 a;
+        __builtin_memcpy(&a, b + ca, 16);
+        return zfw_min3(zfw_min3(zfw_ffbl(a.x ^ c.x), zfw_ffbl(a.y ^ c.y) | 32u, zfw_ffbl(a.z ^ c.z) | 64u),
+                        zfw_ffbl(a.w ^ c.w) | 96u, 128u) >> 3;
+    };
+
+    /* deflateSetDictionary inserts every dictionary string; the last two wait for the first input bytes
+     * (deflate.c:364-381, 1471-1489) */
+    for (uint32_t a = 0; a < dict_len && a + ZC_MIN_MATCH <= E; a += 64u) {
+        uint32_t m = dict_len - a < 64u ? dict_len - a : 64u;
+        if (a + m + ZC_MIN_MATCH - 1u > E) m = E - (ZC_MIN_MATCH - 1u) - a;
+        const uint32_t x = a + lane;
+        uint32_t w = 0;
+        if (lane < m) w = (uint32_t)b[x] | ((uint32_t)b[x + 1] << 8) | ((uint32_t)b[x + 2] << 16);
+        insert_many(a, m, zc_hash3(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, hshift, hmask));
+    }
+
+    uint32_t B = 0, wend = dict_len, p = dict_len;                    /* fill_window's state, see ZcWindow */
+    uint32_t nsym = 0, blk_sym0 = 0, bstart = dict_len, nblk = 0;     /* _tr_tally's and the block table's, see ZcSink */
+    uint32_t symrow = 0;
+    auto flush = [&](uint32_t last) {                                 /* FLUSH_BLOCK_ONLY, deflate.c:1538-1547 */
+        ZcBlock kb;
+        kb.sym_start = blk_sym0; kb.sym_count = nsym - blk_sym0;
+        kb.in_start = bstart; kb.in_len = p - bstart;
+        kb.flags = (last ? ZC_BF_LAST : 0u) | (bstart >= B ? ZC_BF_CANSTORE : 0u);
+        kb.type = 0; kb.bits = 0; kb.hdr_bits = 0; kb.bit_off = 0;
+        blk(nblk++, kb);
+        blk_sym0 = nsym; bstart = p;
+    };
+    /* One iteration of deflate_fast's loop (deflate.c:1641-1711) at p with `look` bytes of lookahead.  `full`: the
+     * lookahead is MIN_LOOKAHEAD or more, so no length is cut short by it and every string has its three bytes. */
+    auto step = [&](const bool full, const uint32_t look) {
+        uint32_t mlen = 0, mdist = 0;
+        uint4 pv = make_uint4(0, 0, 0, 0);
+        if (full || look >= ZC_MIN_MATCH) {
+            pv = load16(p);
+            const uint32_t h0 = ZFW_UNI(hash_at(pv, 0u));
+            /* the bucket as it stands before this string goes in: the slots by lanes 0 .. 31, the count by lane 32 */
+            uint32_t val = 0;
+            if (lane <= ZFR_WAYS) val = lane < ZFR_WAYS ? ring[(uint64_t)h0 * ZFR_WAYS + lane] : cnt[h0];
+            const uint32_t c = __builtin_amdgcn_readlane(val, ZFR_WAYS);
+            if (lane < 2u) { if (lane == 0) ring[(uint64_t)h0 * ZFR_WAYS + (c & (ZFR_WAYS - 1u))] = p; else cnt[h0] = c + 1u; }
+            ZFW_WAVE_FENCE();
+            /* longest_match (deflate.c:1148-1289) with prev_length 2: the head of the chain must not be NIL and at most
+             * MAX_DIST away (:1660), the strings behind it must be nearer (:1158-1159, 1284), the walk takes at most
+             * max_chain of them; they grow older (and lie further back) slot by slot down from the newest */
+            const uint32_t age = (c - 1u - lane) & (ZFR_WAYS - 1u);
+            const bool far = p - B > max_dist;
+            const uint32_t lo = far ? p - max_dist : B;
+            const uint32_t nent = c < chain ? c : chain;
+            const bool valid = lane < ZFR_WAYS && age < nent && val + ((age == 0u && far) ? 1u : 0u) > lo;
+            const uint32_t vm = (uint32_t)__ballot(valid);
+            if (c != 0u && ((vm >> ((c - 1u) & (ZFR_WAYS - 1u))) & 1u)) {
+                const uint32_t cap = full ? ZC_MAX_MATCH : (look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH);
+                uint32_t thr = full ? (nice < ZC_MIN_LOOK ? nice : ZC_MIN_LOOK) : (nice < look ? nice : look);
+                thr = thr < ZC_MIN_MATCH ? ZC_MIN_MATCH : thr;           /* nothing shorter than 3 beats best_len 2 and ends the walk */
+                uint32_t len = 0;
+                if (valid) {
+                    if (p < wide_end) {
+                        len = lcp16v(val, pv);
+                        if (__ballot(len == 16u) != 0ull) {             /* somebody's first 16 bytes are equal */
+                            uint32_t off = 16u;
+                            do {
+                                uint4 cc; __builtin_memcpy(&cc, b + (p + off), 16);
+                                const uint32_t r = lcp16v(val + off, cc);
+                                len = len == off ? off + r : len;      /* a comparison that has ended keeps its length */
+                                off += 16u;
+                            } while (off < cap && __ballot(len == off) != 0ull);
+                        }
+                    } else {
+                        const uint8_t *m = b + val, *sp = b + p;
+#pragma unroll 1
+                        while (len < cap && m[len] == sp[len]) len++;
+                    }
+                    len = len < cap ? len : cap;
+                }
+                /* the reference's rule by age: strictly longer wins, the walk ends at the first string of nice length.
+                 * Bit a of `ends`: the string of age a ends the walk (slot s holds age (c - 1 - s) mod 32) */
+                const uint32_t gm = (uint32_t)__ballot(valid && len >= thr);
+                const uint32_t rv = __brev(gm), sh = c & (ZFR_WAYS - 1u);
+                const uint32_t ends = sh ? ((rv << sh) | (rv >> (32u - sh))) : rv;
+                const uint32_t cut = ends ? (uint32_t)__builtin_ctz(ends) : ZFR_WAYS - 1u;
+                const uint32_t key = (valid && age <= cut) ? ((len << 6) | (63u - age)) : 0u;
+                const uint32_t top = wave_max32(key), best = top >> 6;
+                if (best >= ZC_MIN_MATCH) {
+                    const uint32_t bage = 63u - (top & 63u);
+                    mlen = best; mdist = p - __builtin_amdgcn_readlane(val, (c - 1u - bage) & (ZFR_WAYS - 1u));
+                }
+            }
+        }
+        uint32_t word;
+        const uint32_t p0 = p;
+        if (mlen >= ZC_MIN_MATCH) {
+            word = zc_sym_match(mlen, mdist);
+            if (mlen <= max_insert && (full || look - mlen >= ZC_MIN_MATCH)) {
+                /* the strings inside the match: the first twelve have their bytes in pv, the rest are fetched */
+                const uint32_t m = mlen - 1u;
+                uint32_t done = m < 12u ? m : 12u;
+                insert_many(p0 + 1u, done, hash_at(pv, lane < 12u ? lane + 1u : 0u));
+                while (done < m) {
+                    const uint32_t take = m - done < 13u ? m - done : 13u;
+                    const uint4 v = load16(p0 + 1u + done);
+                    insert_many(p0 + 1u + done, take, hash_at(v, lane < 13u ? lane : 0u));
+                    done += take;
+                }
+            }
+            p = p0 + mlen;
+        } else { word = p0; p = p0 + 1u; }
+        /* _tr_tally (trees.c:1010-1050): symbols leave in rows of 64, lane i & 63 keeps symbol i until the row is full */
+        symrow = lane == (nsym & 63u) ? word : symrow;
+        if ((nsym & 63u) == 63u) symout[(nsym & ~63u) + lane] = symrow;
+        nsym++;
+        if (nsym - blk_sym0 == lim) flush(0);
+    };
+    for (;;) {
+        while (wend - p >= ZC_MIN_LOOK) step(true, ZC_MIN_LOOK);
+        /* fill_window, deflate.c:1390-1494 */
+        if (p - B >= W + (W - ZC_MIN_LOOK)) B += W;
+        const uint64_t cap = (uint64_t)B + 2u * W;
+        wend = E < cap ? E : (uint32_t)cap;
+        const uint32_t look = wend - p;
+        if (look == 0) break;
+        if (look < ZC_MIN_LOOK) step(false, look);
+    }
+    if (g.final) flush(1);
+    else if (nsym != blk_sym0) flush(0);
+    if (lane < (nsym & 63u)) symout[(nsym & ~63u) + lane] = symrow;    /* the last, partial row */
+    if (lane == 0) {
+        J.nblk[lc] = nblk < J.P.max_blocks ? nblk : J.P.max_blocks;
+        J.nsym[lc] = nsym;
+    }
+}
