@@ -460,7 +460,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), amdgp
 #define ZFR_WAYS 32u
 #endif
 
-__global__ __launch_bounds__(64) void k_fastr(ZkJob J)
+__device__ __forceinline__ void zfr_chunk(const ZkJob &J)
 {
     const uint32_t lc = blockIdx.x, lane = threadIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
@@ -657,3 +657,6 @@ __global__ __launch_bounds__(64) void k_fastr(ZkJob J)
         J.nsym[lc] = nsym;
     }
 }
+/* (a second build that fits eight wavefronts to a SIMD, as k_fastw has one, made no difference here: three trips to memory
+ * per step and twice the instructions, not the wavefronts in flight, are what this kernel runs at) */
+__global__ __launch_bounds__(64) void k_fastr(ZkJob J) { zfr_chunk(J); }
