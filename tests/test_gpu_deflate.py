@@ -335,7 +335,7 @@ def test_dictionary_of_any_length_then_several_chunks(engine, dlen):
     """A preset dictionary of any length primes the first chunk; the later chunks see (dictionary ++ data) as history."""
     d = O.corpus(dlen, 0, 300)
     data = O.corpus(3 * 65536 + 99, 0, 301)
-    for level in (1, 6):
+    for level in (1, 2, 3, 6):
         out, lens = _gpu(engine, data, level=level, chunk_size=65536, dictionary=d)
         hist = d + data
         want = b""
