@@ -29,6 +29,9 @@ timeout -k 10 500 python3 bench.py --workload l1_text --chunks-per-gpu 4096 --no
 for w in l9_image_filtered l6_lowent_huff l6_image_rle; do
   timeout -k 10 500 python3 bench.py --workload $w --chunks-per-gpu 4096 --no-cpu-baseline --no-serial-pass > $O/bench_$w.json 2> $O/bench_w.err || { tail -5 $O/bench_w.err; exit 1; }
 done
+for w in l2_text l3_text; do
+  timeout -k 10 500 python3 bench.py --workload $w --no-cpu-baseline --no-serial-pass > $O/bench_$w.json 2> $O/bench_w.err || { tail -5 $O/bench_w.err; exit 1; }
+done
 # 6. the stream API on host buffers
 timeout -k 10 300 python3 -u tests/gpu_api_bench.py 3584 6 > $O/api_host_buffers.txt 2>&1 || { tail -5 $O/api_host_buffers.txt; exit 1; }
 timeout -k 10 300 python3 -u tests/gpu_api_bench.py 3584 1 > $O/api_host_buffers_l1.txt 2>&1 || { tail -5 $O/api_host_buffers_l1.txt; exit 1; }
