@@ -594,10 +594,11 @@ __global__ __launch_bounds__(64) void k_hop(ZkJob J)
     if (lane == 0) { J.nhop[lc] = H; if (nfall) atomicAdd(J.err + 1, nfall); }
 }
 
-/* The same walk for the hop words of k_resolve (no searches of its own), with the dependent LDS read taken off most
- * hops: the 64 hop words from the current position on sit in one register, a hop inside them is a v_readlane and a
- * few scalar instructions (the walk's state is wave-uniform: it lives in scalar registers), and the LDS is read once
- * per window instead of once per hop.  Arrivals are kept one per lane and stored 64 at a time. */
+/* The same walk for the hop words of k_resolve (no searches of its own), 64 positions at a time: lane l holds the
+ * offset that the hop word of position i + l leads to; the walk inside the 64 is a chain of v_readlane in scalar
+ * registers (five instructions a hop) that leaves the set of positions it stood on as a bit mask, and the positions of
+ * that set where a match starts are stored by their own lanes, ranked by the mask.  The hop words come through an LDS
+ * tile that is fetched one tile ahead. */
 __global__ __launch_bounds__(64) void k_hopw(ZkJob J)
 {
     __shared__ uint32_t s_tile[ZK_HOP_TILE];
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64) void k_hopw(ZkJob J)
             *v[r] = q;
         }
     };
-    uint32_t i = 0, H = 0, base = 0xffff0000u, pbase = 0xffff0000u, wb = 0, wlen = 0, w = 0, abuf = 0;
+    uint32_t i = 0, H = 0, base = 0xffff0000u, pbase = 0xffff0000u;
     uint4 p0 = make_uint4(1, 1, 1, 1), p1 = p0;
     while (i < len) {
         if (i - base >= ZK_HOP_TILE) {
@@ -631,22 +632,25 @@ __global__ __launch_bounds__(64) void k_hopw(ZkJob J)
             __syncthreads();
             pbase = base + ZK_HOP_TILE;
             if (pbase < len) fetch(pbase, p0, p1);
-            wlen = 0;
         }
-        if (i - wb >= wlen) {
-            const uint32_t off = i - base;
-            wb = i; wlen = ZK_HOP_TILE - off < 64u ? ZK_HOP_TILE - off : 64u;
-            w = s_tile[off + lane < ZK_HOP_TILE ? off + lane : ZK_HOP_TILE - 1u];
-        }
-        const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)(i - wb));
-        if (h & ZC_HOP_MATCH) {
-            abuf = lane == (H & 63u) ? i : abuf;
-            if ((H & 63u) == 63u) arr[(H & ~63u) + lane] = abuf;
-            H++;
-            i += zc_hop_k(h) + zc_hop_len(h);
-        } else i += h;
+        const uint32_t off = i - base;
+        const uint32_t wlen = ZK_HOP_TILE - off < 64u ? ZK_HOP_TILE - off : 64u;
+        const uint32_t w = s_tile[off + lane < ZK_HOP_TILE ? off + lane : ZK_HOP_TILE - 1u];
+        const bool ism = (w & ZC_HOP_MATCH) != 0;
+        uint32_t step = ism ? zc_hop_k(w) + zc_hop_len(w) : w;
+        if (step == 0) step = 1;                           /* no word of k_resolve is zero; a walk must move */
+        const uint32_t to = lane + step;
+        unsigned long long stood = 0;
+        uint32_t cur = 0;
+        do {
+            stood |= 1ull << cur;
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)to, (int)cur);
+        } while (cur < wlen);
+        const unsigned long long mm = __ballot(ism) & stood;
+        if ((mm >> lane) & 1ull) arr[H + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = i + lane;
+        H += (uint32_t)__popcll(mm);
+        i += cur;
     }
-    if (lane < (H & 63u)) arr[(H & ~63u) + lane] = abuf;
     if (lane == 0) J.nhop[lc] = H;
 }
 
