@@ -499,47 +499,40 @@ __global__ __launch_bounds__(64) void k_parse(ZkJob J)
 /* ------------------------------------------------------------------ k_resolve / k_hop / k_expand
  * The lazy parser (deflate_slow) split into a parallel part, a short serial
  * part and a parallel part; see zc_resolve_pos in zamd_core.h. */
-#define ZK_RESOLVE_TILE 1024u
+#define ZK_RESOLVE_TILE 256u
 struct GRec2 {
     const uint2 *r; uint32_t dict_len;
     __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q) const { uint2 v = r[p - dict_len]; *f = v.x; *q = v.y; }
 };
 
 /* A workgroup takes ZK_RESOLVE_SPAN tiles of its chunk in a row: the chunk's geometry (64-bit arithmetic, the same for
- * every thread) costs more than one position's hop word, so it is worked out once for 8 192 positions, not for 1 024. */
-#define ZK_RESOLVE_SPAN 8u
+ * every thread) costs more than one position's hop word, so it is worked out once for 8 192 positions.  The hop word
+ * of a position where no match starts is the distance to the next one where one does among the 64 positions of its
+ * wavefront, or to the end of those: the wavefronts share nothing and never wait for each other. */
+#define ZK_RESOLVE_SPAN 32u
 __global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t spans_per_chunk)
 {
-    __shared__ unsigned long long s_mask[ZK_RESOLVE_TILE / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t lc = blockIdx.x / spans_per_chunk, span = blockIdx.x % spans_per_chunk;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     const uint32_t E = g.dict_len + g.len;
     GRec2 rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
     uint32_t *const hop = J.hop + (uint64_t)lc * J.P.chunk_size;
+#pragma unroll 2
     for (uint32_t t = 0; t < ZK_RESOLVE_SPAN; t++) {
-        const uint32_t i0 = (span * ZK_RESOLVE_SPAN + t) * ZK_RESOLVE_TILE;
-        if (i0 >= g.len) return;
-        const uint32_t tl = g.len - i0 < ZK_RESOLVE_TILE ? g.len - i0 : ZK_RESOLVE_TILE;
+        const uint32_t i = (span * ZK_RESOLVE_SPAN + t) * ZK_RESOLVE_TILE + tid;
+        if (i - lane >= g.len) return;                   /* the whole wavefront is past the end */
         uint32_t h = 0;
-        if (tid < tl) h = zc_resolve_pos(rec, g.dict_len + i0 + tid, E, J.P);
-        unsigned long long m = __ballot((h & ZC_HOP_MATCH) != 0);
-        if (lane == 0) s_mask[wv] = m;
-        __syncthreads();
-        if (tid < tl && !(h & ZC_HOP_MATCH)) {
-            /* literal: distance to the next position of the tile where a match starts (or to the tile's end) */
-            unsigned long long mm = m & (~0ull << lane);
-            uint32_t next = tl;
-            if (mm) next = wv * 64u + (uint32_t)__ffsll((long long)mm) - 1u;
-            else for (uint32_t w = wv + 1; w < ZK_RESOLVE_TILE / 64; w++) {
-                unsigned long long x = s_mask[w];
-                if (x) { next = w * 64u + (uint32_t)__ffsll((long long)x) - 1u; break; }
-            }
-            if (next > tl) next = tl;
-            h = next - tid;
+        if (i < g.len) h = zc_resolve_pos(rec, g.dict_len + i, E, J.P);
+        const unsigned long long starts = __ballot((h & ZC_HOP_MATCH) != 0);
+        if (!(h & ZC_HOP_MATCH)) {
+            const unsigned long long mm = starts & (~0ull << lane);
+            const uint32_t left = g.len - (i - lane);    /* positions of the chunk from this wavefront's first on */
+            uint32_t next = left < 64u ? left : 64u;
+            if (mm) next = (uint32_t)__ffsll((long long)mm) - 1u;
+            h = next - lane;
         }
-        if (tid < tl) hop[i0 + tid] = h;
-        __syncthreads();                       /* the masks are read before the next tile writes them */
+        if (i < g.len) hop[i] = h;
     }
 }
 
