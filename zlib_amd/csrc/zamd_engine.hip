@@ -72,8 +72,8 @@ struct ZkJob {
  * dictionary), head table in LDS.  The strings must be inserted in position
  * order per hash value, which is all the chains need: the 16 wavefronts of the
  * workgroup split the HASH VALUES between them (hash mod 16), so each wave owns
- * its slice of the head table.  Per round of 1024 positions: every thread hashes
- * one position and files it under the wavefront that owns its hash (a counting
+ * its slice of the head table.  Per round of 4096 positions: every thread hashes
+ * four positions and files them under the wavefronts that own their hashes (a counting
  * sort by owner that keeps position order: rank inside the filing wavefront from
  * a returning LDS add, offsets from the 16 x 16 table of counts, which every
  * wavefront sums for itself), then every
@@ -84,12 +84,25 @@ struct ZkJob {
  * lane order; a violation would show as a chain that runs forwards and raises
  * ZE_CHAIN_ORDER.) */
 #define ZK_CHAIN_THREADS 1024
-#define ZK_CHAIN_ROUND   1024u
+#ifndef ZK_CHAIN_NP
+#define ZK_CHAIN_NP      4u                       /* positions per thread and round */
+#endif
+#define ZK_CHAIN_ROUND   (1024u * ZK_CHAIN_NP)
+#define ZK_CHAIN_WSPAN   (64u * ZK_CHAIN_NP)      /* consecutive positions of a round that one wavefront takes, 64 at a time */
 /* A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load and store of the
  * wave (s_waitcnt vmcnt(0)): with a prefetch in flight that exposes a trip to memory at every barrier.  The data handed
  * between waves here lives in LDS; global loads are consumed by the thread that issued them (the compiler waits for
  * those itself), global stores are read by later kernels only. */
 #define ZK_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+/* inclusive sum over the 16 lanes of a row, one DPP add per step (lanes shifted in from outside the row read zero) */
+__device__ inline uint32_t zk_row_scan16(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);     /* row_shr:1 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);     /* row_shr:2 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);     /* row_shr:4 */
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);     /* row_shr:8 */
+    return x;
+}
 __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
 {
     __shared__ uint32_t head[32768];
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
      * atomics go to one column, and with rows of 16 that column lies in two LDS banks (eight addresses each); rows of 20
      * spread it over eight banks and keep the rows aligned for 16-byte reads */
     __shared__ __attribute__((aligned(16))) uint32_t s_cnt[16][20];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint64_t c = J.chunk0 + blockIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head, J.P.wsize);
     const uint32_t E = g.dict_len + g.len;
@@ -112,51 +125,57 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     const uint8_t *src = J.in + g.dstart;
     uint16_t *pd = J.pdist + (g.dstart - J.pdist_base);
     const uint32_t passes = J.P.hash_bits > 15 ? (1u << (J.P.hash_bits - 15)) : 1u;
-    /* the two aligned words that hold bytes a..a+2, fetched one round ahead.  A dictionary of any length in front
-     * of the first chunk leaves a-coordinate 0 at any address: `mis` is its offset from a dword boundary. */
+    /* the two aligned words that hold bytes a..a+2, fetched one round ahead, without a branch so that nothing waits for
+     * them before the next round uses them.  A dictionary of any length in front of the first chunk leaves a-coordinate 0
+     * at any address: `mis` is its offset from a dword boundary.  Positions past the last string read the last string's
+     * words (and are not hashed); the second word is read only when the string reaches into it: an aligned word that
+     * holds a byte of the input lies in the input's pages. */
     const uint32_t mis = (uint32_t)((uintptr_t)src & 3u);
+    const uint8_t *const srca = src - mis;
     auto fetch = [&](uint32_t a, uint32_t &w0, uint32_t &w1) {
-        w0 = 0; w1 = 0;
-        if (a < Ex) {
-            const uint32_t al = (a + mis) & ~3u;          /* offset of the aligned word from src - mis */
-            if (al >= mis && g.dstart + (al - mis) + 8 <= J.n) { w0 = *(const uint32_t *)(src - mis + al); w1 = *(const uint32_t *)(src - mis + al + 4); }
-            else {
-                uint32_t b3 = (uint32_t)src[a] | ((uint32_t)src[a + 1] << 8) | ((uint32_t)src[a + 2] << 16);
-                uint32_t sh = 8u * ((a + mis) & 3u);
-                w0 = b3 << sh; w1 = sh ? b3 >> (32u - sh) : 0u;
-            }
-        }
+        const uint32_t x = (a < Ex ? a : Ex - 1u) + mis, al = x & ~3u;
+        w0 = *(const uint32_t *)(srca + al);
+        w1 = *(const uint32_t *)(srca + al + ((x & 2u) << 1));
     };
     for (uint32_t pass = 0; pass < passes; pass++) {
         for (uint32_t i = tid; i < 32768; i += ZK_CHAIN_THREADS) head[i] = 0;
         if (tid < 320) (&s_cnt[0][0])[tid] = 0;
-        uint32_t w0, w1;
-        fetch(tid, w0, w1);
+        uint32_t w0[ZK_CHAIN_NP], w1[ZK_CHAIN_NP];
+#pragma unroll
+        for (uint32_t u = 0; u < ZK_CHAIN_NP; u++) { w0[u] = 0; w1[u] = 0; if (Ex) fetch(wv * ZK_CHAIN_WSPAN + u * 64u + lane, w0[u], w1[u]); }
         __syncthreads();
         for (uint32_t r0 = 0; r0 < Ex; r0 += ZK_CHAIN_ROUND) {
-            /* 1. the hash of this thread's position.  A stretch of equal hashes inside one wavefront (a run of one byte
-             *    value, mostly) needs the table twice only: the string that opens it reads the previous occurrence, the
-             *    one that closes it leaves its position behind; every string in between links to its neighbour, one back.
-             *    Only opening and closing strings are filed; `rank` numbers them among those their wavefront files under
-             *    the same owner. */
-            const uint32_t a = r0 + tid;
-            uint32_t hv = 0xffffu, rank = 0;
-            if (a < Ex) {
-                uint32_t b3 = __builtin_amdgcn_alignbyte(w1, w0, (a + mis) & 3u);
-                uint32_t h = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
-                if ((h >> 15) == pass) hv = h & 32767u;
+            /* 1. the hashes of this thread's positions: the wavefront takes a stretch of the round, 64 consecutive positions
+             *    at a time.  A stretch of equal hashes inside one 64 (a run of one byte value, mostly) needs the table twice
+             *    only: the string that opens it reads the previous occurrence, the one that closes it leaves its position
+             *    behind; every string in between links to its neighbour, one back.  Only opening and closing strings are
+             *    filed; `rank` numbers them among those their wavefront files under the same owner, in position order: the
+             *    counting atomics of one 64 number their lanes in lane order, and a wavefront's LDS instructions run in
+             *    program order. */
+            uint32_t hv[ZK_CHAIN_NP], rank[ZK_CHAIN_NP], own[ZK_CHAIN_NP];
+            bool filed[ZK_CHAIN_NP], opens[ZK_CHAIN_NP];
+#pragma unroll
+            for (uint32_t u = 0; u < ZK_CHAIN_NP; u++) {
+                const uint32_t a = r0 + wv * ZK_CHAIN_WSPAN + u * 64u + lane;
+                hv[u] = 0xffffu; rank[u] = 0;
+                if (a < Ex) {
+                    uint32_t b3 = __builtin_amdgcn_alignbyte(w1[u], w0[u], (a + mis) & 3u);
+                    uint32_t h = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
+                    if ((h >> 15) == pass) hv[u] = h & 32767u;
+                }
+                const uint32_t hp = __shfl_up(hv[u], 1), hn = __shfl_down(hv[u], 1);
+                opens[u] = lane == 0 || hp != hv[u];
+                const bool closes = lane == 63 || hn != hv[u];
+                filed[u] = hv[u] != 0xffffu && (opens[u] || closes);
+                s_hash[wv * ZK_CHAIN_WSPAN + u * 64u + lane] = (uint16_t)hv[u];
+                s_link[wv * ZK_CHAIN_WSPAN + u * 64u + lane] = 1;
+                /* the owner mixes all hash bits: the low four alone are the low nibble of the string's third byte */
+                own[u] = (hv[u] ^ (hv[u] >> 5) ^ (hv[u] >> 10)) & 15u;
+                if (filed[u]) rank[u] = atomicAdd(&s_cnt[own[u]][wv], 1u);
+                fetch(a + ZK_CHAIN_ROUND, w0[u], w1[u]);
             }
-            const uint32_t hp = __shfl_up(hv, 1), hn = __shfl_down(hv, 1);
-            const bool opens = lane == 0 || hp != hv, closes = lane == 63 || hn != hv;
-            const bool filed = hv != 0xffffu && (opens || closes);
-            s_hash[tid] = (uint16_t)hv;
-            s_link[tid] = 1;
-            /* the owner mixes all hash bits: the low four alone are the low nibble of the string's third byte */
-            const uint32_t own = (hv ^ (hv >> 5) ^ (hv >> 10)) & 15u;
-            if (filed) rank = atomicAdd(&s_cnt[own][wv], 1u);
-            fetch(a + ZK_CHAIN_ROUND, w0, w1);
             ZK_LDS_BARRIER();
-            /* 2. counts -> offsets, by every wavefront for itself (lane d of every group of 16 takes owner d): where owner
+            /* 2. counts -> offsets, by every wavefront for itself (lane d of every row of 16 takes owner d): where owner
              *    d's stretch of s_sorted starts, and where inside it the positions of this wavefront go */
             uint32_t seg0, seg1;
             {
@@ -169,19 +188,22 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) { if (q + k == wv) before = run; run += n[k]; }
                 }
-                uint32_t incl = run;                                  /* scan of the owners' totals over each group of 16 lanes */
-                for (uint32_t k = 1; k < 16; k <<= 1) { const uint32_t y = __shfl_up(incl, k, 16); if (d >= k) incl += y; }
+                const uint32_t incl = zk_row_scan16(run);             /* scan of the owners' totals over each row of 16 lanes */
                 const uint32_t start = incl - run;
-                /* 3. file the position: lane `own` of this lane's group of 16 holds that owner's numbers */
-                const uint32_t base = __shfl(start + before, own, 16);
-                if (filed) s_sorted[base + rank] = (uint16_t)(tid | (opens ? 0x8000u : 0u));
-                seg0 = __shfl(start, wv, 16);
-                seg1 = __shfl(incl, wv, 16);
+                /* 3. file the positions: lane `own` of this lane's row holds that owner's numbers */
+#pragma unroll
+                for (uint32_t u = 0; u < ZK_CHAIN_NP; u++) {
+                    const uint32_t base = __shfl(start + before, own[u], 16);
+                    if (filed[u]) s_sorted[base + rank[u]] = (uint16_t)((wv * ZK_CHAIN_WSPAN + u * 64u + lane) | (opens[u] ? 0x8000u : 0u));
+                }
+                /* every row holds the same numbers */
+                seg0 = (uint32_t)__builtin_amdgcn_readlane((int)start, (int)wv);
+                seg1 = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)wv);
             }
             ZK_LDS_BARRIER();
             /* 4. every wavefront enters the strings whose hash it owns, in position order */
             for (uint32_t j = seg0 + lane; j < seg1; j += 64u) {
-                const uint32_t e = s_sorted[j], q = e & 1023u, hq = s_hash[q], aq = r0 + q;
+                const uint32_t e = s_sorted[j], q = e & (ZK_CHAIN_ROUND - 1u), hq = s_hash[q], aq = r0 + q;
                 uint32_t old = atomicMax(&head[hq], aq + 1);
                 if (old > aq) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
                 if (e & 0x8000u) {
@@ -191,8 +213,12 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
             }
             if (tid < 320) (&s_cnt[0][0])[tid] = 0;        /* read for the last time in step 2 */
             ZK_LDS_BARRIER();
-            if (a < Ex && a >= out_from && hv != 0xffffu) pd[a] = s_link[tid];
-            /* s_link[tid] and s_hash[tid] are written again by this thread, and read by others a barrier later */
+#pragma unroll
+            for (uint32_t u = 0; u < ZK_CHAIN_NP; u++) {
+                const uint32_t a = r0 + wv * ZK_CHAIN_WSPAN + u * 64u + lane;
+                if (a < Ex && a >= out_from && hv[u] != 0xffffu) pd[a] = s_link[wv * ZK_CHAIN_WSPAN + u * 64u + lane];
+            }
+            /* s_link and s_hash of these positions are written again by this thread, and read by others a barrier later */
         }
         __syncthreads();
     }
