@@ -627,17 +627,12 @@ __global__ __launch_bounds__(64) void k_hopw(ZkJob J)
     uint32_t *arr = J.arr + (uint64_t)lc * (J.P.chunk_size / 2);
     const uint32_t len = __builtin_amdgcn_readfirstlane(g.len);
     /* the hop words of one tile, eight per lane, on their way from memory: the tile behind the current one is fetched
-     * while the current one is walked */
+     * while the current one is walked.  A chunk's row of hop words is a whole number of tiles long (the chunk size is a
+     * multiple of 16 KiB), so a tile is loaded as it stands, without a branch that would wait for the load; the words
+     * behind the chunk's last position are never stood on. */
     auto fetch = [&](uint32_t tb, uint4 &v0, uint4 &v1) {
-        uint4 *v[2] = {&v0, &v1};
-#pragma unroll
-        for (uint32_t r = 0; r < 2; r++) {
-            const uint32_t idx = tb + r * 256u + lane * 4u;
-            uint4 q = make_uint4(1, 1, 1, 1);
-            if (idx + 4u <= len) q = *(const uint4 *)(hop + idx);
-            else { if (idx < len) q.x = hop[idx]; if (idx + 1 < len) q.y = hop[idx + 1]; if (idx + 2 < len) q.z = hop[idx + 2]; }
-            *v[r] = q;
-        }
+        v0 = *(const uint4 *)(hop + tb + lane * 4u);
+        v1 = *(const uint4 *)(hop + tb + 256u + lane * 4u);
     };
     uint32_t i = 0, H = 0, base = 0xffff0000u, pbase = 0xffff0000u;
     uint4 p0 = make_uint4(1, 1, 1, 1), p1 = p0;
@@ -653,7 +648,9 @@ __global__ __launch_bounds__(64) void k_hopw(ZkJob J)
             if (pbase < len) fetch(pbase, p0, p1);
         }
         const uint32_t off = i - base;
-        const uint32_t wlen = ZK_HOP_TILE - off < 64u ? ZK_HOP_TILE - off : 64u;
+        uint32_t wlen = ZK_HOP_TILE - off < 64u ? ZK_HOP_TILE - off : 64u;
+        if (len - i < wlen) wlen = len - i;
+        wlen = (uint32_t)__builtin_amdgcn_readfirstlane((int)wlen);      /* the walk's loop condition stays on the scalar unit */
         const uint32_t w = s_tile[off + lane < ZK_HOP_TILE ? off + lane : ZK_HOP_TILE - 1u];
         const bool ism = (w & ZC_HOP_MATCH) != 0;
         uint32_t step = ism ? zc_hop_k(w) + zc_hop_len(w) : w;
