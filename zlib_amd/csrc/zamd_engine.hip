@@ -247,6 +247,18 @@ struct LdsPd {
 /* Input bytes of a-coordinates a0 .. a0 + nbytes - 1 of a chunk into LDS (zero outside the input). */
 __device__ inline void zk_load_window(const ZkJob &J, const ZcChunkGeom &g, int64_t a0, uint32_t *s_win, uint32_t nbytes, uint32_t tid)
 {
+    if (a0 >= 0 && g.dstart + (uint64_t)a0 + nbytes <= J.n && nbytes / 16u >= 3u * ZK_MATCH_THREADS && nbytes / 16u < 4u * ZK_MATCH_THREADS) {
+        /* the whole image lies inside the input (every tile but a chunk's first few and the input's last): the loads of a
+         * thread are all in flight before the first is stored */
+        const uint4 *src = (const uint4 *)(J.in + g.dstart + a0);
+        const uint4 q0 = src[tid], q1 = src[tid + ZK_MATCH_THREADS], q2 = src[tid + 2u * ZK_MATCH_THREADS];
+        uint4 q3 = make_uint4(0, 0, 0, 0);
+        const bool more = tid + 3u * ZK_MATCH_THREADS < nbytes / 16u;
+        if (more) q3 = src[tid + 3u * ZK_MATCH_THREADS];
+        ((uint4 *)s_win)[tid] = q0; ((uint4 *)s_win)[tid + ZK_MATCH_THREADS] = q1; ((uint4 *)s_win)[tid + 2u * ZK_MATCH_THREADS] = q2;
+        if (more) ((uint4 *)s_win)[tid + 3u * ZK_MATCH_THREADS] = q3;
+        return;
+    }
     for (uint32_t v = tid; v < nbytes / 16; v += ZK_MATCH_THREADS) {
         int64_t a = a0 + 16 * (int64_t)v;
         int64_t abs = (int64_t)g.dstart + a;
@@ -265,8 +277,28 @@ __device__ inline void zk_load_window(const ZkJob &J, const ZcChunkGeom &g, int6
 }
 /* Chain links of a-coordinates a0 .. a0 + count - 1 into LDS; "none" (0) is stored as 0xffff so that adding it to a
  * distance always exceeds MAX_DIST. */
+__device__ inline uint4 zk_links_none(uint4 q)
+{
+    uint32_t t[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if ((t[k] & 0xffffu) == 0) t[k] |= 0xffffu;
+        if ((t[k] >> 16) == 0) t[k] |= 0xffff0000u;
+    }
+    return make_uint4(t[0], t[1], t[2], t[3]);
+}
 __device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64_t a0, uint16_t *s_pd, uint32_t count, uint32_t tid)
 {
+    if (a0 >= 0 && g.dstart + (uint64_t)a0 - J.pdist_base + count <= J.pdist_len && count == 6u * 8u * ZK_MATCH_THREADS) {
+        /* all links exist: six loads per thread in flight together */
+        const uint4 *src = (const uint4 *)(J.pdist + (g.dstart + (uint64_t)a0 - J.pdist_base));
+        uint4 q[6];
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++) q[k] = src[tid + k * ZK_MATCH_THREADS];
+#pragma unroll
+        for (uint32_t k = 0; k < 6; k++) ((uint4 *)s_pd)[tid + k * ZK_MATCH_THREADS] = zk_links_none(q[k]);
+        return;
+    }
     for (uint32_t v = tid; v < count / 8; v += ZK_MATCH_THREADS) {
         int64_t a = a0 + 8 * (int64_t)v;
         uint4 q = make_uint4(0, 0, 0, 0);
