@@ -822,13 +822,37 @@ __global__ __launch_bounds__(ZK_PLAN_THREADS) void k_plan(ZkJob J)
     if (tid < 4) cost[tid] = 0;
     __syncthreads();
     /* _tr_tally frequency counts (trees.c:1017-1030) */
-    for (uint32_t i = tid; i < b.sym_count; i += ZK_PLAN_THREADS) {
-        if (b.flags & ZC_BF_IMPLICIT) { atomicAdd(&hist[src[b.in_start + i]], 1u); continue; }
-        uint32_t s = sym[i];
-        if (!(s & ZC_SYM_MATCH)) atomicAdd(&hist[src[s]], 1u);
-        else {
-            atomicAdd(&hist[257u + zc_len_code((s >> 16) & 0xffu)], 1u);
-            atomicAdd(&hist[288u + zc_dist_code((s & 0xffffu) - 1u)], 1u);
+    if (b.flags & ZC_BF_IMPLICIT) {
+        for (uint32_t i = tid; i < b.sym_count; i += ZK_PLAN_THREADS) atomicAdd(&hist[src[b.in_start + i]], 1u);
+    } else if (b.sym_count >= 8u) {
+        /* eight consecutive symbols per lane at a time, loaded without a branch (the last lanes of the block step back so
+         * that their eight end with it, and skip what the lanes before them have counted), then the eight literal bytes
+         * (a match reads byte 0): two trips to memory per 512 symbols */
+        for (uint32_t i0 = 0; i0 < b.sym_count; i0 += 8u * ZK_PLAN_THREADS) {
+            const uint32_t want = i0 + tid * 8u, from = want + 8u <= b.sym_count ? want : b.sym_count - 8u;
+            const uint4 sa = *(const uint4 *)(sym + from), sb = *(const uint4 *)(sym + from + 4u);
+            const uint32_t s[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            uint32_t lit[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) lit[u] = src[(s[u] & ZC_SYM_MATCH) ? 0u : s[u]];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                if (from + u < want) continue;
+                if (!(s[u] & ZC_SYM_MATCH)) atomicAdd(&hist[lit[u]], 1u);
+                else {
+                    atomicAdd(&hist[257u + zc_len_code((s[u] >> 16) & 0xffu)], 1u);
+                    atomicAdd(&hist[288u + zc_dist_code((s[u] & 0xffffu) - 1u)], 1u);
+                }
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < b.sym_count; i += ZK_PLAN_THREADS) {
+            const uint32_t s = sym[i];
+            if (!(s & ZC_SYM_MATCH)) atomicAdd(&hist[src[s]], 1u);
+            else {
+                atomicAdd(&hist[257u + zc_len_code((s >> 16) & 0xffu)], 1u);
+                atomicAdd(&hist[288u + zc_dist_code((s & 0xffffu) - 1u)], 1u);
+            }
         }
     }
     __syncthreads();
