@@ -385,10 +385,20 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
                 len = x0 ? zc_ctz32(x0) >> 3 : x1 ? 4u + (zc_ctz32(x1) >> 3) : x2 ? 8u + (zc_ctz32(x2) >> 3) : x3 ? 12u + (zc_ctz32(x3) >> 3) : 16u;
             }
             if (len == 16u) {
+                /* long matches (runs, repeated records) 16 bytes a round trip as well: a wavefront stays in this loop as
+                 * long as its longest comparison does */
                 while (len < cap) {
-                    uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
-                    if (x) { len += zc_ctz32(x) >> 3; break; }
-                    len += 4;
+                    const uint32_t oc = cur + len - la0, op = p + len - la0, ic = oc >> 2, ip = op >> 2;
+                    uint32_t c[9], q[9], x[8];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) { c[k] = s_win[ic + k]; q[k] = s_win[ip + k]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[k] = __builtin_amdgcn_alignbyte(c[k + 1], c[k], oc) ^ __builtin_amdgcn_alignbyte(q[k + 1], q[k], op);
+                    uint32_t n = 32u;
+#pragma unroll
+                    for (int k = 7; k >= 0; k--) n = x[k] ? 4u * (uint32_t)k + (zc_ctz32(x[k]) >> 3) : n;
+                    len += n;
+                    if (n < 32u) break;
                 }
             }
             if (len > cap) len = cap;
