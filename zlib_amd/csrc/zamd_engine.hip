@@ -38,6 +38,9 @@
 #define ZK_HALO      32768u
 #define ZK_WIN_BYTES (ZK_HALO + ZK_TILE + 320u)
 #define ZK_MATCH_THREADS 1024
+#ifndef ZK_MATCH_C
+#define ZK_MATCH_ASM 1                     /* k_match's candidate round written by hand; -DZK_MATCH_C builds the C++ form of the same round */
+#endif
 #ifndef ZK_MATCH_STEPS
 #define ZK_MATCH_STEPS 8                     /* candidate steps between two looks at the number of stopped lanes */
 #endif
@@ -466,6 +469,153 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
         int32_t wm = walking;
         int32_t kc = kk & walking;
         uint32_t xlast = 1u;
+#ifdef ZK_MATCH_ASM
+        /* The same eight-step round by hand: a lane that stops is taken out of EXEC by the comparison that stops it
+         * (its candidate, count and last peek stay as that step left them) and EXEC is restored after the round, so a
+         * step needs no mask register, no multiply and no scalar instruction: 10 vector + 2 LDS instructions.  The
+         * reach test runs on r = plim - c, which the step's own sum carries to the next step. */
+        {
+            const uint32_t wbase = (uint32_t)(uintptr_t)s_win;
+            uint32_t ca = c + wbase;
+            const uint32_t l0 = (uint32_t)(uintptr_t)s_pd - 2u * (best - 2u) - 2u * wbase;
+            int32_t r = plim - (int32_t)c;
+            asm volatile(
+            "s_mov_b64 s[90:91], exec\n\t"
+            "v_cmp_gt_i32_e32 vcc, 0, %[wm]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_mov_b32 s92, 8\n\t"
+            "1:\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 v57, %[r], v54\n\t"
+            "v_bitop3_b32 v56, v57, %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 %[r], v57, v54\n\t"
+            "v_bitop3_b32 v56, %[r], %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 v57, %[r], v54\n\t"
+            "v_bitop3_b32 v56, v57, %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 %[r], v57, v54\n\t"
+            "v_bitop3_b32 v56, %[r], %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 v57, %[r], v54\n\t"
+            "v_bitop3_b32 v56, v57, %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 %[r], v57, v54\n\t"
+            "v_bitop3_b32 v56, %[r], %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 v57, %[r], v54\n\t"
+            "v_bitop3_b32 v56, v57, %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "v_and_b32 v50, -4, %[c]\n\t"
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t"
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t"
+            "ds_read_u16 v54, v51\n\t"
+            "v_add_u32 %[kc], 1, %[kc]\n\t"
+            "s_waitcnt lgkmcnt(1)\n\t"
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t"
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t"
+            "v_sub_u32 v55, 0, %[x]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_add_u32 %[r], v57, v54\n\t"
+            "v_bitop3_b32 v56, %[r], %[kc], v55 bitop3:0x80\n\t"
+            "v_cmpx_gt_i32_e32 vcc, 0, v56\n\t"
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            "s_bcnt1_i32_b64 s93, exec\n\t"
+            "s_cmp_le_u32 s93, %[keep]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_add_i32 s92, s92, -1\n\t"
+            "s_cmp_lg_u32 s92, 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_mov_b64 s[94:95], exec\n\t"
+            "s_mov_b64 exec, s[90:91]\n\t"
+            "v_mov_b32 %[wm], 0\n\t"
+            "s_mov_b64 exec, s[94:95]\n\t"
+            "v_mov_b32 %[wm], -1\n\t"
+            "s_mov_b64 exec, s[90:91]\n\t"
+            : [c] "+v"(ca), [kc] "+v"(kc), [x] "+v"(xlast), [r] "+v"(r), [wm] "+v"(wm)
+            : [l0] "v"(l0), [scan] "v"(scan3), [mask] "s"(0x00ffffffu), [keep] "n"(64 - ZK_MATCH_THRESH)
+            : "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc");
+            c = ca - wbase;
+        }
+#else
 #pragma unroll 1
         for (int it = 0; it < 64 / ZK_MATCH_STEPS; it++) {
 #pragma unroll
@@ -487,6 +637,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
             }
             if (__popcll(__ballot(wm == 0)) >= ZK_MATCH_THRESH) break;
         }
+#endif
         if (walking < 0) kk = kc;
         cur = c - peek_off;
         /* a walk that stopped in this round stands on the candidate that stopped it: it is parked if that
