@@ -106,6 +106,19 @@ __device__ inline uint32_t zk_row_scan16(uint32_t x)
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);     /* row_shr:8 */
     return x;
 }
+/* inclusive sum over the 64 lanes of a wavefront with DPP row shifts and broadcasts (no LDS) */
+__device__ inline uint32_t zk_wave_scan(uint32_t v)
+{
+    uint32_t s = v;
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);    /* row_shr:1 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);    /* row_shr:2 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true);    /* row_shr:3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, true);    /* row_shr:4, banks 1-3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, true);    /* row_shr:8, banks 2-3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, true);    /* row_bcast:15 into rows 1, 3 */
+    s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, true);    /* row_bcast:31 into rows 2, 3 */
+    return s;
+}
 __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
 {
     __shared__ uint32_t head[32768];
@@ -903,8 +916,7 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
         if (j <= H) { lits = (a - prev) + k; cnt = lits + (j < H ? 1u : 0u); }
         if (j == H) tail_lits = lits;
         /* exclusive scan of the symbol counts */
-        uint32_t incl = cnt;
-        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        const uint32_t incl = zk_wave_scan(cnt);
         if (lane == 63) s_wsum[wv] = incl;
         __syncthreads();
         uint32_t woff = 0, total = 0;
@@ -1171,31 +1183,41 @@ __global__ __launch_bounds__(ZK_EMIT_THREADS) void k_emit(ZkJob J)
     const uint32_t *sym = J.sym + (uint64_t)lc * J.P.chunk_size + b.sym_start;
     uint64_t bitpos = bit0 + 3 + b.hdr_bits;
     const uint32_t total = b.sym_count + 1;       /* + END_BLOCK */
+    /* The tile's symbols and literal bytes are on their way while the tile before it is coded: symbol words two tiles
+     * ahead, the literal bytes they point at one tile ahead, loaded without a branch (past the block's end: its last
+     * symbol, not used), and the barriers of the loop wait for LDS only. */
+    const bool implicit = (b.flags & ZC_BF_IMPLICIT) != 0;
+    const uint32_t last_sym = b.sym_count ? b.sym_count - 1u : 0u;
+    auto load_sym = [&](uint32_t i) -> uint32_t { return (implicit || !b.sym_count) ? 0u : sym[i < last_sym ? i : last_sym]; };
+    auto load_lit = [&](uint32_t i, uint32_t s) -> uint32_t {
+        const uint32_t a = implicit ? b.in_start + (i < last_sym ? i : last_sym) : ((s & ZC_SYM_MATCH) ? 0u : s);
+        return src[a];
+    };
+    uint32_t s_cur = load_sym(tid), s_n1 = load_sym(ZK_EMIT_THREADS + tid);
+    uint32_t lit_cur = load_lit(tid, s_cur);
     for (uint32_t t = 0; t < total; t += ZK_EMIT_THREADS) {
         uint32_t i = t + tid;
+        const uint32_t lit_n1 = load_lit(i + ZK_EMIT_THREADS, s_n1);
+        const uint32_t s_n2 = load_sym(i + 2u * ZK_EMIT_THREADS);
         uint64_t v = 0; uint32_t n = 0;
-        if (i < b.sym_count) {
-            uint32_t s, lit = 0;
-            if (b.flags & ZC_BF_IMPLICIT) { s = 0; lit = src[b.in_start + i]; }
-            else { s = sym[i]; if (!(s & ZC_SYM_MATCH)) lit = src[s]; }
-            n = zc_sym_bits(s, lit, ltab, dtab, &v);
-        } else if (i == b.sym_count) { v = ltab[ZC_END_BLOCK] & 0xffffu; n = ltab[ZC_END_BLOCK] >> 16; }
+        if (i < b.sym_count) n = zc_sym_bits(s_cur, lit_cur, ltab, dtab, &v);
+        else if (i == b.sym_count) { v = ltab[ZC_END_BLOCK] & 0xffffu; n = ltab[ZC_END_BLOCK] >> 16; }
+        s_cur = s_n1; s_n1 = s_n2; lit_cur = lit_n1;
         /* exclusive prefix sum of code lengths over the 256-symbol tile */
-        uint32_t incl = n;
-        for (uint32_t d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+        const uint32_t incl = zk_wave_scan(n);
         if (lane == 63) wsum[wv] = incl;
         for (uint32_t k = tid; k < ZK_STAGE_WORDS; k += ZK_EMIT_THREADS) stage[k] = 0;
-        __syncthreads();
+        ZK_LDS_BARRIER();
         uint32_t woff = 0, tile_bits = 0;
         for (uint32_t k = 0; k < ZK_EMIT_THREADS / 64; k++) { uint32_t ws = wsum[k]; if (k < wv) woff += ws; tile_bits += ws; }
         const uint32_t sh = (uint32_t)bitpos & 31u;
         lds_or_bits(stage, sh + woff + incl - n, v, n);
-        __syncthreads();
+        ZK_LDS_BARRIER();
         const uint32_t nwords = (sh + tile_bits + 31) >> 5;
         const uint64_t w0 = bitpos >> 5;
         for (uint32_t k = tid; k < nwords; k += ZK_EMIT_THREADS) { uint32_t x = stage[k]; if (x) atomicOr(&out32[w0 + k], x); }
         bitpos += tile_bits;
-        __syncthreads();
+        ZK_LDS_BARRIER();
     }
 }
 
