@@ -478,16 +478,24 @@ __device__ __forceinline__ void zfr_chunk(const ZkJob &J)
     /* a comparison may read 16 bytes at a time while 258 + 16 bytes from p on lie inside the buffer */
     const uint32_t wide_end = readable > 274u ? (uint32_t)(readable - 274u < 0xfffffff0ull ? readable - 274u : 0xfffffff0ull) : 0u;
 
-    /* the 16 bytes from a-coordinate x on (x wave-uniform), zero past the buffer's end */
-    auto load16 = [&](uint32_t x) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if ((uint64_t)x + 16u <= readable) __builtin_memcpy(&v, b + x, 16);
-        else {
-            uint32_t t[4] = {0, 0, 0, 0};
-            for (uint32_t i = 0; i < 16u && (uint64_t)x + i < readable; i++) t[i >> 2] |= (uint32_t)b[x + i] << (8u * (i & 3u));
-            v = make_uint4(t[0], t[1], t[2], t[3]);
+    /* The input from the parse's position on is kept in a register: lane l holds the dword at a-coordinate wb + 4 l (zero
+     * past the buffer's end), 256 bytes in all, so that the 16 bytes a step starts from are five v_readlane and four
+     * v_alignbyte instead of a trip to memory; the register is loaded again when the position leaves its first 240 bytes. */
+    uint32_t wb = 0x80000000u, wreg = 0;                 /* no a-coordinate is within 240 bytes of this */
+    auto window16 = [&](uint32_t x) {
+        if (x - wb > 239u) {
+            wb = x & ~3u;
+            const uint64_t a = (uint64_t)wb + 4u * lane;
+            uint32_t w = 0;
+            if (a + 4u <= readable) __builtin_memcpy(&w, b + a, 4);
+            else for (uint32_t i = 0; i < 4u && a + i < readable; i++) w |= (uint32_t)b[a + i] << (8u * i);
+            wreg = w;
         }
-        return v;
+        const uint32_t o = x - wb, d = o >> 2;
+        const uint32_t s0 = __builtin_amdgcn_readlane(wreg, d), s1 = __builtin_amdgcn_readlane(wreg, d + 1u), s2 = __builtin_amdgcn_readlane(wreg, d + 2u),
+                       s3 = __builtin_amdgcn_readlane(wreg, d + 3u), s4 = __builtin_amdgcn_readlane(wreg, d + 4u);
+        return make_uint4(__builtin_amdgcn_alignbyte(s1, s0, o), __builtin_amdgcn_alignbyte(s2, s1, o),
+                          __builtin_amdgcn_alignbyte(s3, s2, o), __builtin_amdgcn_alignbyte(s4, s3, o));
     };
     /* hash of the string that starts i bytes into v (i per lane, at most 12) */
     auto hash_at = [&](const uint4 &v, uint32_t i) {
@@ -560,7 +568,7 @@ __device__ __forceinline__ void zfr_chunk(const ZkJob &J)
         uint32_t mlen = 0, mdist = 0;
         uint4 pv = make_uint4(0, 0, 0, 0);
         if (full || look >= ZC_MIN_MATCH) {
-            pv = load16(p);
+            pv = window16(p);
             const uint32_t h0 = ZFW_UNI(hash_at(pv, 0u));
             /* the bucket as it stands before this string goes in: the slots by lanes 0 .. 31, the count by lane 32 */
             uint32_t val = 0;
@@ -626,7 +634,7 @@ __device__ __forceinline__ void zfr_chunk(const ZkJob &J)
                 insert_many(p0 + 1u, done, hash_at(pv, lane < 12u ? lane + 1u : 0u));
                 while (done < m) {
                     const uint32_t take = m - done < 13u ? m - done : 13u;
-                    const uint4 v = load16(p0 + 1u + done);
+                    const uint4 v = window16(p0 + 1u + done);
                     insert_many(p0 + 1u + done, take, hash_at(v, lane < 13u ? lane : 0u));
                     done += take;
                 }
