@@ -665,6 +665,6 @@ __device__ __forceinline__ void zfr_chunk(const ZkJob &J)
         J.nsym[lc] = nsym;
     }
 }
-/* (a second build that fits eight wavefronts to a SIMD, as k_fastw has one, made no difference here: three trips to memory
+/* (a second build that fits eight wavefronts to a SIMD, as k_fastw has one, made no difference here: the trips to memory
  * per step and twice the instructions, not the wavefronts in flight, are what this kernel runs at) */
 __global__ __launch_bounds__(64) void k_fastr(ZkJob J) { zfr_chunk(J); }
