@@ -232,25 +232,30 @@ __device__ __forceinline__ void zfw_chunk(const ZkJob &J)
     GBlk blk; blk.b = J.blk + (uint64_t)lc * J.P.max_blocks; blk.cap = J.P.max_blocks; blk.err = J.err; blk.lane = lane;
     /* a comparison may read 16 bytes at a time while 258 + 16 bytes from p on lie inside the buffer */
     const uint32_t wide_end = readable > 274u ? (uint32_t)(readable - 274u < 0xfffffff0ull ? readable - 274u : 0xfffffff0ull) : 0u;
-    /* the last position whose four bytes can be read with one load */
-    const uint32_t quad_end = readable >= 4u ? (uint32_t)(readable - 4u < 0xfffffff0ull ? readable - 4u : 0xfffffff0ull) : 0u;
     const bool in_ways = lane < ways;
     const uint32_t inv_lane = 3u - lane, is0 = lane == 0 ? 1u : 0u;
 
     /* ---- the batch: hashes and buckets of positions q0 .. q0 + 63, one position per lane */
     uint32_t q0 = 0, h_cur, last_cur = ZFW_NONE;
     uint4 c_cur;
+    uint32_t wb = 0x80000000u, wreg = 0;                 /* no a-coordinate is within 256 bytes of this */
     auto load_batch = [&](uint32_t qb, uint32_t &h, uint4 &c) {
         const uint32_t a = qb + lane;
         const bool ok = a + ZC_MIN_MATCH <= E;
-        uint32_t w = 0;
-        if (ok) {
-            if (readable >= 4u) {                                     /* the three bytes of a string that ends with the buffer come from one byte further down */
-                const uint32_t a4 = a < quad_end ? a : quad_end;
-                __builtin_memcpy(&w, b + a4, 4);
-                w >>= 8u * (a - a4);
-            } else w = (uint32_t)b[a] | ((uint32_t)b[a + 1] << 8) | ((uint32_t)b[a + 2] << 16);
+        /* the batch's bytes come from a register that holds the 256 bytes from wb on (lane l: the dword at wb + 4 l, zero
+         * past the buffer's end) and is loaded again when a batch would reach past it: one trip to memory for three
+         * batches or so instead of one for each */
+        if (qb - wb > 188u) {
+            wb = qb & ~3u;
+            const uint64_t wa = (uint64_t)wb + 4u * lane;
+            uint32_t t = 0;
+            if (wa + 4u <= readable) __builtin_memcpy(&t, b + wa, 4);
+            else for (uint32_t i = 0; i < 4u && wa + i < readable; i++) t |= (uint32_t)b[wa + i] << (8u * i);
+            wreg = t;
         }
+        const uint32_t wo = qb - wb + lane, wd = wo >> 2;
+        const uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)__builtin_amdgcn_ds_bpermute((int)((wd + 1u) << 2), (int)wreg),
+                                                      (uint32_t)__builtin_amdgcn_ds_bpermute((int)(wd << 2), (int)wreg), wo);
         h = ok ? zc_hash3(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, hshift, hmask) : ZFW_NONE;
         c = make_uint4(0, 0, 0, 0);
         if (ok) c = tab[h];
