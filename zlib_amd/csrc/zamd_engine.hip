@@ -119,6 +119,19 @@ __device__ inline uint32_t zk_wave_scan(uint32_t v)
     s += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, true);    /* row_bcast:31 into rows 2, 3 */
     return s;
 }
+/* inclusive maximum over the 64 lanes of a wavefront, the same way */
+__device__ inline uint32_t zk_wave_scan_max(uint32_t v)
+{
+    uint32_t s = v;
+    s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+    s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+    s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x113, 0xf, 0xf, true));
+    s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x114, 0xf, 0xe, true));
+    s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x118, 0xf, 0xc, true));
+    s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x142, 0xa, 0xf, true));
+    s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, true));
+    return s;
+}
 __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
 {
     __shared__ uint32_t head[32768];
@@ -887,7 +900,8 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
 {
     __shared__ uint32_t s_off[ZK_EXPAND_THREADS + 1], s_lit0[ZK_EXPAND_THREADS], s_lits[ZK_EXPAND_THREADS];
     __shared__ uint32_t s_word[ZK_EXPAND_THREADS], s_mpos[ZK_EXPAND_THREADS], s_end[ZK_EXPAND_THREADS];
-    __shared__ uint32_t s_wsum[ZK_EXPAND_THREADS / 64];
+    __shared__ uint32_t s_wsum[ZK_EXPAND_THREADS / 64], s_wmax[ZK_EXPAND_THREADS / 64];
+    __shared__ __attribute__((aligned(8))) uint16_t s_own[4 * ZK_EXPAND_THREADS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t lc = blockIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
@@ -928,19 +942,41 @@ __global__ __launch_bounds__(ZK_EXPAND_THREADS) void k_expand(ZkJob J)
         s_lit0[tid] = prev; s_lits[tid] = lits;
         s_word[tid] = j < H ? zc_sym_match(L, D) : 0u; s_mpos[tid] = a + k;
         __syncthreads();
-        for (uint32_t x = tid; x < total; x += ZK_EXPAND_THREADS) {
-            uint32_t lo = 0, hi = ZK_EXPAND_THREADS;          /* last q with s_off[q] <= x */
-            while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= x) lo = mid; else hi = mid; }
-            const uint32_t o = x - s_off[lo];
-            uint32_t word, pos, endpos;
-            if (o < s_lits[lo]) { pos = s_lit0[lo] + o; word = pos; endpos = pos + 1; }
-            else { word = s_word[lo]; pos = s_mpos[lo]; endpos = pos + ((word >> 16) & 0xffu) + 3u; }
-            const uint32_t sidx = base_sym + x;
-            sym[sidx] = word;
-            if ((sidx + 1) % lim == 0) {
-                uint32_t b = (sidx + 1) / lim - 1;
-                if (b < J.P.max_blocks) { blk[b].bits = endpos; blk[b].hdr_bits = pos + top_off; }
+        /* which hop a symbol belongs to: every hop marks its first symbol, and a running maximum over the marks carries
+         * the owner to the symbols behind it (1 024 symbols at a time, four per thread) */
+        uint32_t carry = 0;                                   /* owner + 1 of the last symbol of the 1 024 before */
+        for (uint32_t cx = 0; cx < total; cx += 4u * ZK_EXPAND_THREADS) {
+            *(uint2 *)&s_own[4u * tid] = make_uint2(0, 0);
+            __syncthreads();
+            { const uint32_t so = s_off[tid] - cx; if (cnt != 0u && so < 4u * ZK_EXPAND_THREADS) s_own[so] = (uint16_t)(tid + 1u); }
+            __syncthreads();
+            const uint2 mk = *(const uint2 *)&s_own[4u * tid];
+            uint32_t m[4] = {mk.x & 0xffffu, mk.x >> 16, mk.y & 0xffffu, mk.y >> 16};
+            m[1] = max(m[1], m[0]); m[2] = max(m[2], m[1]); m[3] = max(m[3], m[2]);
+            const uint32_t incl_m = zk_wave_scan_max(m[3]);
+            if (lane == 63) s_wmax[wv] = incl_m;
+            __syncthreads();
+            uint32_t before = carry, all = carry;
+            for (uint32_t w = 0; w < ZK_EXPAND_THREADS / 64; w++) { const uint32_t xm = s_wmax[w]; if (w < wv) before = max(before, xm); all = max(all, xm); }
+            before = max(before, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl_m, 0x138, 0xf, 0xf, true));   /* wave_shr:1: the lanes before this one */
+            carry = all;
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t x = cx + 4u * tid + u;
+                if (x >= total) break;
+                const uint32_t lo = max(m[u], before) - 1u;
+                const uint32_t o = x - s_off[lo];
+                uint32_t word, pos, endpos;
+                if (o < s_lits[lo]) { pos = s_lit0[lo] + o; word = pos; endpos = pos + 1; }
+                else { word = s_word[lo]; pos = s_mpos[lo]; endpos = pos + ((word >> 16) & 0xffu) + 3u; }
+                const uint32_t sidx = base_sym + x;
+                sym[sidx] = word;
+                if ((sidx + 1) % lim == 0) {
+                    uint32_t b = (sidx + 1) / lim - 1;
+                    if (b < J.P.max_blocks) { blk[b].bits = endpos; blk[b].hdr_bits = pos + top_off; }
+                }
             }
+            __syncthreads();                                  /* s_own and s_wmax are written again */
         }
         base_sym += total;
         endp = s_end[ZK_EXPAND_THREADS - 1];
