@@ -752,10 +752,26 @@ struct GRec2 {
     __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q) const { uint2 v = r[p - dict_len]; *f = v.x; *q = v.y; }
 };
 
-/* A workgroup takes ZK_RESOLVE_SPAN tiles of its chunk in a row: the chunk's geometry (64-bit arithmetic, the same for
- * every thread) costs more than one position's hop word, so it is worked out once for 8 192 positions.  The hop word
- * of a position where no match starts is the distance to the next one where one does among the 64 positions of its
- * wavefront, or to the end of those: the wavefronts share nothing and never wait for each other. */
+/* The records of three positions in a row in registers, the others' from memory */
+struct GRec2Three {
+    const uint2 *r; uint32_t dict_len, p0; uint2 a, b, c;
+    __device__ void operator()(uint32_t p, uint32_t *f, uint32_t *q) const
+    {
+        const uint32_t d = p - p0;
+        if (d == 0) { *f = a.x; *q = a.y; }
+        else if (d == 1) { *f = b.x; *q = b.y; }
+        else if (d == 2) { *f = c.x; *q = c.y; }
+        else { const uint2 v = r[p - dict_len]; *f = v.x; *q = v.y; }
+    }
+};
+
+/* A workgroup takes 8 192 positions of its chunk in a row: the chunk's geometry (64-bit arithmetic, the same for every
+ * thread) costs more than one position's hop word, so it is worked out once for all of them.  A thread takes two
+ * positions next to each other: one 16-byte load brings both records, the first position's lazy look finds the second's
+ * record in a register and the second's finds the next thread's first (a DPP shift; lane 63 loads it), so that the
+ * look most chains end with makes no trip to memory.  The hop word of a position where no match starts is the distance
+ * to the next one where one does among the 128 positions of its wavefront, or to the end of those: the wavefronts share
+ * nothing and never wait for each other. */
 #define ZK_RESOLVE_SPAN 32u
 __global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t spans_per_chunk)
 {
@@ -763,23 +779,37 @@ __global__ __launch_bounds__(ZK_RESOLVE_TILE) void k_resolve(ZkJob J, uint32_t s
     const uint32_t lc = blockIdx.x / spans_per_chunk, span = blockIdx.x % spans_per_chunk;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
     const uint32_t E = g.dict_len + g.len;
-    GRec2 rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
+    GRec2Three rec; rec.r = J.rec + (g.dstart + g.dict_len - J.rec_base); rec.dict_len = g.dict_len;
     uint32_t *const hop = J.hop + (uint64_t)lc * J.P.chunk_size;
-#pragma unroll 2
-    for (uint32_t t = 0; t < ZK_RESOLVE_SPAN; t++) {
-        const uint32_t i = (span * ZK_RESOLVE_SPAN + t) * ZK_RESOLVE_TILE + tid;
-        if (i - lane >= g.len) return;                   /* the whole wavefront is past the end */
-        uint32_t h = 0;
-        if (i < g.len) h = zc_resolve_pos(rec, g.dict_len + i, E, J.P);
-        const unsigned long long starts = __ballot((h & ZC_HOP_MATCH) != 0);
-        if (!(h & ZC_HOP_MATCH)) {
-            const unsigned long long mm = starts & (~0ull << lane);
-            const uint32_t left = g.len - (i - lane);    /* positions of the chunk from this wavefront's first on */
-            uint32_t next = left < 64u ? left : 64u;
-            if (mm) next = (uint32_t)__ffsll((long long)mm) - 1u;
-            h = next - lane;
-        }
-        if (i < g.len) hop[i] = h;
+    for (uint32_t t = 0; t < ZK_RESOLVE_SPAN / 2u; t++) {
+        const uint32_t wi = (span * (ZK_RESOLVE_SPAN / 2u) + t) * (2u * ZK_RESOLVE_TILE) + 2u * (tid - lane);   /* the wavefront's first position */
+        if (wi >= g.len) return;
+        const uint32_t i0 = wi + 2u * lane;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        uint2 e = make_uint2(0, 0);
+        if (i0 + 2u <= g.len) v = *(const uint4 *)(rec.r + i0);
+        else if (i0 < g.len) { const uint2 x = rec.r[i0]; v.x = x.x; v.y = x.y; }
+        if (lane == 63u && i0 + 2u < g.len) e = rec.r[i0 + 2u];
+        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(e.x), "+v"(e.y));      /* all loads are made before one is looked at */
+        uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, 0x130, 0xf, 0xf, true);    /* wave_shl:1: the next lane's */
+        uint32_t ny = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, 0x130, 0xf, 0xf, true);
+        if (lane == 63u) { nx = e.x; ny = e.y; }
+        rec.p0 = g.dict_len + i0; rec.a = make_uint2(v.x, v.y); rec.b = make_uint2(v.z, v.w); rec.c = make_uint2(nx, ny);
+        uint32_t h0 = 0, h1 = 0;
+        if (i0 < g.len) h0 = zc_resolve_pos(rec, g.dict_len + i0, E, J.P);
+        if (i0 + 1u < g.len) h1 = zc_resolve_pos(rec, g.dict_len + i0 + 1u, E, J.P);
+        /* positions without a match start: how far to the next one (position 2 l + e of the wavefront's 128 is lane l's e) */
+        const unsigned long long s0 = __ballot((h0 & ZC_HOP_MATCH) != 0), s1 = __ballot((h1 & ZC_HOP_MATCH) != 0);
+        const unsigned long long above = (~0ull << lane) << 1;
+        const unsigned long long m0 = s0 & above, m1 = s1 & above;
+        const uint32_t left = g.len - wi;
+        uint32_t np = left < 128u ? left : 128u;
+        if (m0) np = min(np, 2u * ((uint32_t)__ffsll((long long)m0) - 1u));
+        if (m1) np = min(np, 2u * ((uint32_t)__ffsll((long long)m1) - 1u) + 1u);
+        if (!(h1 & ZC_HOP_MATCH)) h1 = np - (2u * lane + 1u);
+        if (!(h0 & ZC_HOP_MATCH)) h0 = (h1 & ZC_HOP_MATCH) ? 1u : np - 2u * lane;
+        if (i0 + 1u < g.len) *(uint2 *)(hop + i0) = make_uint2(h0, h1);
+        else if (i0 < g.len) hop[i0] = h0;
     }
 }
 
