@@ -231,13 +231,24 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
             }
             ZK_LDS_BARRIER();
             /* 4. every wavefront enters the strings whose hash it owns, in position order */
-            for (uint32_t j = seg0 + lane; j < seg1; j += 64u) {
-                const uint32_t e = s_sorted[j], q = e & (ZK_CHAIN_ROUND - 1u), hq = s_hash[q], aq = r0 + q;
-                uint32_t old = atomicMax(&head[hq], aq + 1);
-                if (old > aq) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
-                if (e & 0x8000u) {
-                    uint32_t d = old ? aq + 1 - old : 0;
-                    s_link[q] = (uint16_t)(d > 32767u ? 0u : d);
+            /* two entries per lane at a time (the second 64 further on: the same lane's next one, so that entries of one hash
+             * value still reach the table in position order — a wavefront's LDS instructions run in program order) */
+            for (uint32_t j = seg0 + lane; j < seg1; j += 128u) {
+                const bool two = j + 64u < seg1;
+                const uint32_t e0 = s_sorted[j], e1 = two ? s_sorted[j + 64u] : 0u;
+                const uint32_t q0 = e0 & (ZK_CHAIN_ROUND - 1u), q1 = e1 & (ZK_CHAIN_ROUND - 1u);
+                const uint32_t h0 = s_hash[q0], h1 = s_hash[q1], a0 = r0 + q0, a1 = r0 + q1;
+                const uint32_t old0 = atomicMax(&head[h0], a0 + 1);
+                uint32_t old1 = 0;
+                if (two) old1 = atomicMax(&head[h1], a1 + 1);
+                if (old0 > a0 || (two && old1 > a1)) atomicOr(J.err, (uint32_t)ZE_CHAIN_ORDER);
+                if (e0 & 0x8000u) {
+                    const uint32_t d = old0 ? a0 + 1 - old0 : 0;
+                    s_link[q0] = (uint16_t)(d > 32767u ? 0u : d);
+                }
+                if (two && (e1 & 0x8000u)) {
+                    const uint32_t d = old1 ? a1 + 1 - old1 : 0;
+                    s_link[q1] = (uint16_t)(d > 32767u ? 0u : d);
                 }
             }
             if (tid < 320) (&s_cnt[0][0])[tid] = 0;        /* read for the last time in step 2 */
