@@ -75,8 +75,9 @@ struct ZkJob {
  * dictionary), head table in LDS.  The strings must be inserted in position
  * order per hash value, which is all the chains need: the 16 wavefronts of the
  * workgroup split the HASH VALUES between them (hash mod 16), so each wave owns
- * its slice of the head table.  Per round of 4096 positions: every thread hashes
- * four positions and files them under the wavefronts that own their hashes (a counting
+ * its slice of the head table.  Per round of 5120 positions (what fits beside the
+ * table in 160 KiB of LDS): every thread hashes
+ * five positions and files them under the wavefronts that own their hashes (a counting
  * sort by owner that keeps position order: rank inside the filing wavefront from
  * a returning LDS add, offsets from the 16 x 16 table of counts, which every
  * wavefront sums for itself), then every
@@ -88,7 +89,7 @@ struct ZkJob {
  * ZE_CHAIN_ORDER.) */
 #define ZK_CHAIN_THREADS 1024
 #ifndef ZK_CHAIN_NP
-#define ZK_CHAIN_NP      4u                       /* positions per thread and round */
+#define ZK_CHAIN_NP      5u                       /* positions per thread and round */
 #endif
 #define ZK_CHAIN_ROUND   (1024u * ZK_CHAIN_NP)
 #define ZK_CHAIN_WSPAN   (64u * ZK_CHAIN_NP)      /* consecutive positions of a round that one wavefront takes, 64 at a time */
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
             for (uint32_t j = seg0 + lane; j < seg1; j += 128u) {
                 const bool two = j + 64u < seg1;
                 const uint32_t e0 = s_sorted[j], e1 = two ? s_sorted[j + 64u] : 0u;
-                const uint32_t q0 = e0 & (ZK_CHAIN_ROUND - 1u), q1 = e1 & (ZK_CHAIN_ROUND - 1u);
+                const uint32_t q0 = e0 & 0x7fffu, q1 = e1 & 0x7fffu;
                 const uint32_t h0 = s_hash[q0], h1 = s_hash[q1], a0 = r0 + q0, a1 = r0 + q1;
                 const uint32_t old0 = atomicMax(&head[h0], a0 + 1);
                 uint32_t old1 = 0;
