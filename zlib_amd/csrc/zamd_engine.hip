@@ -382,13 +382,35 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     uint2 *rec = J.rec + (g.dstart + t0 - J.rec_base);
     const uint32_t lane = tid & 63u;
     if (rle) {
+        const uint32_t la0r = (uint32_t)a0;
         for (;;) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&s_next, 64u);
             base = __shfl(base, 0);
             if (base >= tlen) break;
             uint32_t i = base + lane;
-            if (i < tlen) { uint32_t r = zc_rle_pos(win, t0 + i, E); rec[i] = make_uint2(r, r); }
+            if (i < tlen) {
+                /* zc_rle_pos, 16 bytes of the run per LDS round trip instead of 4 */
+                const uint32_t pp = t0 + i, look = E - pp;
+                uint32_t r = 0;
+                if (look >= ZC_MIN_MATCH && pp != 0) {
+                    const uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH;
+                    const uint32_t pat = (win.load4(pp - 1u) & 0xffu) * 0x01010101u;
+                    uint32_t len = 0;
+                    while (len < cap) {
+                        const uint32_t o = pp + len - la0r, k = o >> 2;
+                        const uint32_t w0 = s_win[k], w1 = s_win[k + 1], w2 = s_win[k + 2], w3 = s_win[k + 3], w4 = s_win[k + 4];
+                        const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, o) ^ pat, x1 = __builtin_amdgcn_alignbyte(w2, w1, o) ^ pat;
+                        const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, o) ^ pat, x3 = __builtin_amdgcn_alignbyte(w4, w3, o) ^ pat;
+                        const uint32_t n = x0 ? zc_ctz32(x0) >> 3 : x1 ? 4u + (zc_ctz32(x1) >> 3) : x2 ? 8u + (zc_ctz32(x2) >> 3) : x3 ? 12u + (zc_ctz32(x3) >> 3) : 16u;
+                        len += n;
+                        if (n < 16u) break;
+                    }
+                    if (len > cap) len = cap;
+                    r = len >= ZC_MIN_MATCH ? (len | (1u << 16)) : 0u;
+                }
+                rec[i] = make_uint2(r, r);
+            }
         }
         return;
     }
