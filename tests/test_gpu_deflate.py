@@ -40,6 +40,7 @@ for lvl in GPU_LEVELS:
 for strat in (1, 2, 3, 4):
     CASES.append((3, 700001, 6, strat, 8, 1 << 18))
     CASES.append((2, 150000, 9, strat, 8, 65536))
+CASES.append((4, 400000, 6, 3, 8, 131072))      # Z_RLE over long runs (the mixed corpus has stretches of one byte value)
 for mem in (1, 2, 4, 7, 9):
     CASES.append((4, 400000, 6, 0, mem, 131072))
 for mem in (1, 3, 8):
