@@ -56,6 +56,13 @@ for n in (0, 1, 2, 3, 4, 261, 262, 263, 16383, 16384, 32767, 32768, 32769, 65274
     CASES.append((0, n, 1, 0, 8, 65536))
     CASES.append((4, n, 3, 0, 8, 32768))
     CASES.append((1, n, 0, 0, 8, 65536))
+# chunks of 4 MiB (a-coordinates beyond 2^21), and sizes around the 240- and 256-byte reloads of the input registers of levels 1-3
+for lvl in (1, 2, 6):
+    CASES.append((4, 5 * (1 << 20) + 123, lvl, 0, 8, 1 << 22))
+for n in (188, 189, 239, 240, 241, 255, 256, 257, 479, 480, 481, 735):
+    for lvl in (1, 2, 3):
+        CASES.append((0, n, lvl, 0, 8, 32768))
+        CASES.append((2, 32768 + n, lvl, 0, 8, 32768))
 for mem in (1, 5, 9):
     CASES.append((4, 300000, 0, 0, mem, 131072))
     CASES.append((1, (1 << 20) + 70000, 0, 4, mem, 1 << 20))
