@@ -253,7 +253,7 @@ def main():
     names = ["chain", "match", "parse", "plan", "layout", "emit", "call"]
     kt = {nm: eng.timing_ms(i) for i, nm in enumerate(names)}
     dominant = "match" if kt["match"][1] else "parse"     # levels 1-3 have no separate match kernel
-    kernel_name = "k_match" if dominant == "match" else ("k_fastw" if level == 1 else "k_fast")
+    kernel_name = "k_match" if dominant == "match" else ("k_fastw" if level == 1 else "k_fastr" if level in (2, 3) else "k_parse")
     roofline = None
     kt_serial = None
     if not args.no_serial_pass:
