@@ -67,11 +67,13 @@ int zamd_deflate_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t chun
 
 /*
  * The same for one shard of a larger input (multi-GPU sharding by chunk range):
- * the head_dict_len bytes (a multiple of 16, at most 32768) in front of d_in are
+ * the head_dict_len bytes (any length up to the window size, 32768 at windowBits 15) in front of d_in are
  * device-resident too and are the dictionary of the shard's first chunk, exactly
  * as the previous 32 KiB are for every later chunk — the tail of the previous
  * shard, or a preset dictionary (deflateSetDictionary, deflate.c:323).  Pass
- * finish = 1 only on the shard that holds the end of the input.
+ * finish = 1 only on the shard that holds the end of the input.  d_in itself must be 16-byte aligned; a
+ * head_dict_len that is not a multiple of 16 leaves the dictionary's first byte unaligned, and the kernels' 16-byte
+ * loads of the first chunk's window then run in the hardware's unaligned mode (slower for that chunk, same bytes).
  */
 int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t n, uint32_t head_dict_len, uint32_t chunk_size,
                            int level, int strategy, int mem_level, int finish,
@@ -126,7 +128,8 @@ int zamd_crc32_dev(zamd_engine *e, uint32_t crc, const void *d_in, uint64_t n, u
 
 /*
  * zamd_adler32_dev and zamd_crc32_dev in one call that allocates nothing: no counterpart in the reference; it is for
- * callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).
+ * callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc).  It launches on the engine's own
+ * stream and waits for it, so it cannot itself be recorded into a HIP graph.
  * The per-slice partial checksums go to a fixed array inside the library's code object (128 KiB per GPU, held until the
  * process ends) instead of a hipMalloc'ed buffer, and are folded on the GPU: d_result (DEVICE memory, 2 x uint32) receives
  * adler32(adler, d_in, n) and crc32(crc, d_in, n).  n is at most 16 GiB (16384 slices of 1 MiB): larger inputs are
@@ -172,6 +175,9 @@ int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64_t comp_byt
  *           d_head_window is the previous shard's tail window (ignored when has_head_window was 0).
  *   finish  completes d_out.
  * Rank r: begin; receive the window from r-1; tail; send it to r+1; finish.
+ * The three calls share the engine's inflate workspace with every other inflate entry point: any other inflate call
+ * of this engine between begin and finish ends the sharded inflate, and its tail / finish calls then return
+ * ZAMD_STREAM_ERROR.
  */
 int zamd_inflate_shard_begin_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
                                  uint32_t chunk_size, int has_head_window, void *d_out, uint64_t n_out, int64_t *bad_chunk);
@@ -182,8 +188,9 @@ int zamd_inflate_shard_finish_dev(zamd_engine *e, const void *d_head_window);
  * the batches are cut the same way but all issued to one stream, so that every kernel runs alone on the GPU, which
  * is what per-kernel timing needs (zamd_last_timing_ms then returns durations that add up, not overlapping spans). */
 int zamd_engine_set_streams(zamd_engine *e, int nstreams, int serialize);
-/* The number of streams deflate calls are spread over at present (0: no engine). */
+/* The number of streams deflate calls are spread over at present (0: no engine), and the serialize flag. */
 int zamd_engine_streams(zamd_engine *e);
+int zamd_engine_serialized(zamd_engine *e);
 
 /*
  * General form: inflate a list of segments of one raw deflate stream, one GPU

@@ -131,3 +131,76 @@ def test_symbol_versions_and_soname():
         ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
         line = [ln for ln in ldd.splitlines() if "libzamd_z.so" in ln]
         assert line and os.path.realpath(line[0].split("=>")[1].split("(")[0].strip()) == os.path.realpath(so), ldd
+
+
+def test_a_copy_that_runs_out_of_memory_leaves_no_shared_state():
+    """deflateCopy / inflateCopy with an allocator that refuses in the middle of the copy (the mem_limit of
+    test/infcover.c:55-234): Z_MEM_ERROR, dest->state is NULL (deflate.c:1036-1053) or dest untouched
+    (inflate.c:1455-1466), everything the copy got went back, and the source still works.  No GPU: input shorter
+    than a batch only waits in the state."""
+    import ctypes as C
+    import _zapi as Z
+    l = Z.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p; libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    live, ctl = {}, {"allow": 1 << 30}
+
+    def zalloc(opaque, items, size):
+        if ctl["allow"] <= 0:
+            return None
+        ctl["allow"] -= 1
+        p = libc.malloc(items * size)
+        live[p] = items * size
+        return p
+
+    def zfree(opaque, p):
+        assert p in live, "freed a block that did not come from zalloc (or twice)"
+        del live[p]
+        libc.free(p)
+
+    za, zf = Z.ALLOC(zalloc), Z.FREE(zfree)
+    data = bytes(range(256)) * 1200
+    src = C.create_string_buffer(data, len(data))
+    obuf = C.create_string_buffer(1 << 16)
+    s = Z.ZStream()
+    s.zalloc, s.zfree = C.cast(za, C.c_void_p), C.cast(zf, C.c_void_p)
+    assert l.deflateInit2_(C.byref(s), 6, 8, 15, 8, 0, Z.VERSION, Z.SZ) == Z.Z_OK
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(data), C.addressof(obuf), 1 << 16
+    assert l.deflate(C.byref(s), Z.Z_NO_FLUSH) == Z.Z_OK and s.avail_in == 0      # buffered, mid-stream
+    before = dict(live)
+    src_state = s.state
+    for allow in (0, 1, 2):                  # the state block itself, then the copy's buffers
+        d = Z.ZStream()
+        ctl["allow"] = allow
+        rc = l.deflateCopy(C.byref(d), C.byref(s))
+        ctl["allow"] = 1 << 30
+        if rc == Z.Z_OK:
+            assert d.state and d.state != src_state
+            assert l.deflateEnd(C.byref(d)) in (Z.Z_OK, Z.Z_DATA_ERROR)
+        else:
+            assert rc == Z.Z_MEM_ERROR and not d.state, (allow, rc, d.state)
+        assert live == before, "a failed copy kept memory"
+    assert l.deflateEnd(C.byref(s)) == Z.Z_DATA_ERROR and not live            # still BUSY: deflate.c:1006
+
+    i = Z.ZStream()
+    i.zalloc, i.zfree = C.cast(za, C.c_void_p), C.cast(zf, C.c_void_p)
+    assert l.inflateInit2_(C.byref(i), 15, Z.VERSION, Z.SZ) == Z.Z_OK
+    half = bytes.fromhex("789c")                                              # a zlib header and nothing more
+    hsrc = C.create_string_buffer(half, len(half))
+    i.next_in, i.avail_in, i.next_out, i.avail_out = C.addressof(hsrc), len(half), C.addressof(obuf), 1 << 16
+    assert l.inflate(C.byref(i), Z.Z_NO_FLUSH) in (Z.Z_OK, Z.Z_BUF_ERROR)
+    before = dict(live)
+    for allow in (0, 1):
+        d = Z.ZStream()
+        d.total_in = 777                                                       # must survive a failed copy
+        ctl["allow"] = allow
+        rc = l.inflateCopy(C.byref(d), C.byref(i))
+        ctl["allow"] = 1 << 30
+        if rc == Z.Z_OK:
+            assert d.state and d.state != i.state
+            assert l.inflateEnd(C.byref(d)) == Z.Z_OK
+        else:
+            assert rc == Z.Z_MEM_ERROR and not d.state and d.total_in == 777
+        assert live == before
+    assert l.inflateEnd(C.byref(i)) == Z.Z_OK and not live

@@ -20,7 +20,7 @@
  *   k_layout  per chunk bit layout, k_scan exclusive scan -> output offsets
  *   k_emit    compress_block: prefix sums over code lengths, LDS bit staging,
  *             OR into the zeroed output
- * Levels 1-3: k_fast (zamd_fast_impl.h) replaces chain/match/parse.
+ * Levels 1-3: k_fastw / k_fastr / k_fast (zamd_fast_impl.h, by chain budget) replace chain/match/parse.
  * Inflate: zamd_inflate_impl.h.
  */
 #include <hip/hip_runtime.h>
@@ -1659,6 +1659,7 @@ extern "C" int zamd_engine_set_streams(zamd_engine *e, int nstreams, int seriali
 }
 
 extern "C" int zamd_engine_streams(zamd_engine *e) { return e ? e->nstreams : 0; }
+extern "C" int zamd_engine_serialized(zamd_engine *e) { return e ? e->serialize : 0; }
 
 extern "C" int zamd_engine_window_bits(zamd_engine *e, int window_bits)
 {
@@ -1755,8 +1756,6 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     int rc = fill_params(P, level, strategy, mem_level, chunk_size, e->wbits);
     if (rc) return rc;
     if (head_dict_len > P.wsize) return ZAMD_STREAM_ERROR;
-    P.tail = e->tail_mode; e->tail_mode = ZC_TAIL_SYNC;
-    e->pend_bits = 0; e->pend_val = 0; e->data_type = 2;
     if (e->tuned && level != 0) {
         P.good = e->tune[0]; P.lazy = e->tune[1]; P.nice = e->tune[2]; P.chain = e->tune[3];
         /* deflate_fast always searches with prev_length 2, so a good_length of 2 or less quarters every walk's budget
@@ -1766,8 +1765,11 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (P.parser == ZC_PARSE_FAST && P.chain > 64) return ZAMD_STREAM_ERROR;
     }
     out_cap &= ~15ull;
+    /* the call's arguments are in order: from here on it consumes the one-shot settings (tail, primed bits), both at once */
+    P.tail = e->tail_mode; e->tail_mode = ZC_TAIL_SYNC;
     const uint32_t prime_bits = e->prime_bits, prime_val = e->prime_val;
     e->prime_bits = 0; e->prime_val = 0;
+    e->pend_bits = 0; e->pend_val = 0; e->data_type = 2;
     const auto host_t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(e->device));
     const uint64_t total_chunks = n ? (n + chunk_size - 1) / chunk_size : 1;

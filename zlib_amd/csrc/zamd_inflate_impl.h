@@ -795,6 +795,10 @@ static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems, bool r
 {
     if (!e->inf) { e->inf = new (std::nothrow) ZiState(); if (!e->inf) return ZAMD_MEM_ERROR; }
     ZiState *z = e->inf;
+    /* every inflate entry point comes through here before it touches d_segs, d_mlist or d_stage: a sharded inflate that
+     * was begun and not finished ends here (its tail and finish calls then report ZAMD_STREAM_ERROR instead of resolving
+     * against buffers that belong to another call) */
+    z->pending = false;
     if (!z->d_res) HIPCHK(hipMalloc((void **)&z->d_res, 16));
     if (z->seg_cap < nseg) {
         hipFree(z->d_segs); hipFree(z->d_marks); z->d_segs = nullptr; z->d_marks = nullptr; z->seg_cap = 0;

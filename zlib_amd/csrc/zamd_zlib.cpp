@@ -16,6 +16,7 @@
 #include "../../include/zamd_zlib.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -275,16 +276,24 @@ int batch_compute(z_streamp strm, DState *s, zamd_engine *e, Batch &b, Trace &tr
     uint8_t *d_in = slot_in(b.slot), *d_out = slot_out(b.slot);
     int rc = 0;
     b.total = 0;
-    if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
-    if (rc == 0) rc = zamd_engine_window_bits(e, s->w_bits);
-    if (rc == 0 && s->prime_bits) { rc = zamd_engine_prime(e, (int)s->prime_bits, (int)s->prime_val); s->prime_bits = 0; s->prime_val = 0; }
-    if (rc == 0 && !b.finish && b.tail != ZAMD_TAIL_SYNC) { rc = zamd_engine_tail(e, b.tail); s->index_ok = false; }
     const uint64_t nch = n ? (n + s->chunk_size - 1) / s->chunk_size : 1;
     uint64_t *d_tab = nullptr;
-    if (rc == 0 && s->index_on && s->index_ok) {
+    const bool odd_tail = !b.finish && b.tail != ZAMD_TAIL_SYNC;
+    // everything that can fail without the engine comes first: the engine is shared by all streams, and what is set on
+    // it below is one-shot state that the call which follows must consume
+    if (s->index_on && s->index_ok && !odd_tail) {
         if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, (nch + 1) * 8 > HIST ? (nch + 1) * 8 : HIST) != Z_OK) return ZAMD_MEM_ERROR;
         d_tab = g_gpu.d_off;
     }
+    struct EngineReset {       // whatever happens below, the next stream finds the engine as it expects it
+        zamd_engine *e;
+        ~EngineReset() { zamd_engine_tune(e, 0, 0, 0, 0); zamd_engine_window_bits(e, 15); zamd_engine_prime(e, 0, 0); zamd_engine_tail(e, ZAMD_TAIL_SYNC); }
+    } engine_reset = {e};
+    const uint32_t prime_bits = s->prime_bits, prime_val = s->prime_val;
+    if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
+    if (rc == 0) rc = zamd_engine_window_bits(e, s->w_bits);
+    if (rc == 0 && prime_bits) rc = zamd_engine_prime(e, (int)prime_bits, (int)prime_val);
+    if (rc == 0 && odd_tail) { rc = zamd_engine_tail(e, b.tail); s->index_ok = false; }
     if (rc == 0)
         rc = zamd_deflate_shard_dev(e, d_in + HIST, n, b.head, s->chunk_size, s->level, s->strategy,
                                     s->mem_level, b.finish, d_out, b.bound, d_tab, &b.total);
@@ -298,10 +307,10 @@ int batch_compute(z_streamp strm, DState *s, zamd_engine *e, Batch &b, Trace &tr
             s->index.push_back((uint32_t)raw);
         }
     }
-    if (s->tuned) zamd_engine_tune(e, 0, 0, 0, 0);      // the engine is shared by all streams
-    zamd_engine_window_bits(e, 15);
     if (rc == 0) {
-        // bits behind the last whole byte stay in the bit buffer (bi_flush, trees.c:1169-1181): they lead the next block
+        // the stream's pending bits went out in front of this call's first chunk; the bits behind the call's last whole
+        // byte stay in the bit buffer (bi_flush, trees.c:1169-1181): they lead the next block.  A call that failed
+        // leaves the stream's bits where they were.
         int pb = 0, pv = 0;
         zamd_engine_pending_bits(e, &pb, &pv);
         s->prime_bits = (uint32_t)pb; s->prime_val = (uint32_t)pv;
@@ -402,8 +411,8 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
     int err = 0;
     // transfers start when the engine call they run beside has queued its kernels (see zamd_engine_on_launched)
     struct Hook { std::mutex *mu; std::condition_variable *cv; uint64_t *launched; } hook = {&mu, &cv, &launched};
-    const int streams_before = zamd_engine_streams(e);
-    if (streams_before > 3) zamd_engine_set_streams(e, 3, 0);        // the fourth hardware queue is the transfers'
+    const int streams_before = zamd_engine_streams(e), serialized_before = zamd_engine_serialized(e);
+    if (streams_before > 3) zamd_engine_set_streams(e, 3, serialized_before);        // the fourth hardware queue is the transfers'
     zamd_engine_on_launched(e, [](void *p) { Hook *h = (Hook *)p; { std::lock_guard<std::mutex> g(*h->mu); ++*h->launched; } h->cv->notify_all(); }, &hook);
     uint8_t *const dst0 = strm->next_out;
     uint64_t out_total = 0;
@@ -420,6 +429,16 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
             if (rc) return;
         }
     });
+    // should the second thread not start, the first is told to stop and joined before the exception travels on
+    struct JoinOnUnwind {
+        std::thread &t; std::mutex &mu; std::condition_variable &cv; int &err; zamd_engine *e; int streams, serialized; bool armed;
+        ~JoinOnUnwind() {
+            if (!armed) return;
+            if (t.joinable()) { { std::lock_guard<std::mutex> g(mu); if (!err) err = ZAMD_MEM_ERROR; } cv.notify_all(); t.join(); }
+            zamd_engine_on_launched(e, nullptr, nullptr);
+            zamd_engine_set_streams(e, streams, serialized);
+        }
+    } up_guard = {up, mu, cv, err, e, streams_before, serialized_before, true};
     std::thread down([&] {
         uint64_t at = 0;
         for (uint64_t i = 0; i < count; i++) {
@@ -433,6 +452,7 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
             if (rc) return;
         }
     });
+    up_guard.armed = false;
     uint64_t done = 0;
     for (uint64_t i = 0; i < count; i++) {
         { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || (uploaded > i && downloaded + 2 > i); }); if (err) break; }
@@ -447,7 +467,7 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
     cv.notify_all();
     up.join(); down.join();
     zamd_engine_on_launched(e, nullptr, nullptr);
-    zamd_engine_set_streams(e, streams_before, 0);
+    zamd_engine_set_streams(e, streams_before, serialized_before);
     if (tr.on) for (uint64_t i = 0; i < count; i++) { char b[64]; snprintf(b, sizeof b, " {up %.1f down %.1f}", up_ms[i], down_ms[i]); tr.line += b; }
     tr.done("deflate batches, pipelined");
     // what was compressed and downloaded before a failure stays in the stream, as after a failing run_batch in a row of them
@@ -786,9 +806,13 @@ static int deflateCopy_body(z_streamp dest, z_streamp source) {
     DState *ss = dstate(source);
     if (!ss || dest == Z_NULL) return Z_STREAM_ERROR;
     memcpy((void *)dest, (const void *)source, sizeof(z_stream));
+    dest->state = Z_NULL;                          // never the source's state, whatever fails below (deflate.c:1036-1053)
     void *mem = dest->zalloc(dest->opaque, 1, (uInt)sizeof(DState));
-    if (mem == Z_NULL) { dest->state = Z_NULL; return Z_MEM_ERROR; }
-    DState *ds = new (mem) DState(*ss);
+    if (mem == Z_NULL) return Z_MEM_ERROR;
+    DState *ds;
+    // the copy's buffers come from the caller's zalloc and may be refused: give the state's block back then
+    try { ds = new (mem) DState(*ss); }
+    catch (...) { dest->zfree(dest->opaque, mem); throw; }
     dest->state = (struct internal_state *)ds;
     return Z_OK;
 }
@@ -1492,8 +1516,11 @@ static int inflateCopy_body(z_streamp dest, z_streamp source) {
     if (dest == Z_NULL || !ss || source->zalloc == (alloc_func)0 || source->zfree == (free_func)0) return Z_STREAM_ERROR;
     void *mem = source->zalloc(source->opaque, 1, (uInt)sizeof(IState));
     if (mem == Z_NULL) return Z_MEM_ERROR;
+    IState *ds;
+    // dest is written only once the copy exists (inflate.c:1455-1466 frees what it got and leaves dest alone)
+    try { ds = new (mem) IState(*ss); }
+    catch (...) { source->zfree(source->opaque, mem); throw; }
     memcpy((void *)dest, (const void *)source, sizeof(z_stream));
-    IState *ds = new (mem) IState(*ss);
     dest->state = (struct internal_state *)ds;
     return Z_OK;
 }
@@ -1585,7 +1612,7 @@ int compress(Bytef *dest, uLongf *destLen, const Bytef *source, uLong sourceLen)
 // adler32() and crc32() cannot report an error through their return value (zlib.h:1569-1617), and this library can
 // fail where the reference cannot (no GPU, no device memory).  A failure is therefore made loud: a line on stderr,
 // a sticky error code (zamd_z_last_error), and the caller's running value comes back unchanged.
-static int g_sticky_error = 0;
+static std::atomic<int> g_sticky_error{0};
 static uLong checksum_failed(int crc, uLong start, int code, const char *what) {
     g_sticky_error = code;
     fprintf(stderr, "zamd_z: %s() failed (%s, code %d): the returned value is the running value it was given, not a checksum\n",
@@ -1607,7 +1634,7 @@ static uLong checksum_host_buf(int crc, uLong start, const Bytef *buf, uInt len)
 }
 
 // 0, or the code of the last failure of a call that has no way to report one (adler32, crc32); reading clears it.
-int zamd_z_last_error(void) { int e = g_sticky_error; g_sticky_error = 0; return e; }
+int zamd_z_last_error(void) { return g_sticky_error.exchange(0); }
 
 uLong adler32(uLong adler, const Bytef *buf, uInt len) { return checksum_host_buf(0, adler, buf, len); }
 uLong crc32(uLong crc, const Bytef *buf, uInt len) { return checksum_host_buf(1, crc, buf, len); }
