@@ -84,6 +84,30 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
             pdist[a] = (uint16_t)(d > 32767 ? 0 : d);
         }
     }
+    /* k_chain in its other two modes: links of the exact three-byte chains and of the four-byte chains */
+    std::vector<uint16_t> pdist3e(n + 4, 0);
+    {
+        std::vector<uint64_t> head((size_t)1 << 15, 0);
+        for (uint64_t a = 0; a + 3 <= n; a++) {
+            uint32_t w = (uint32_t)in[a] | ((uint32_t)in[a + 1] << 8) | ((uint32_t)in[a + 2] << 16);
+            uint32_t h = zc_hash3e(w);
+            uint64_t old = head[h]; head[h] = a + 1;
+            uint64_t d = old ? a + 1 - old : 0;
+            pdist3e[a] = (uint16_t)(d > 32767 ? 0 : d);
+        }
+    }
+    std::vector<uint16_t> pdist4(n + 4, 0);
+    {
+        std::vector<uint64_t> head((size_t)1 << 15, 0);
+        for (uint64_t a = 0; a + 4 <= n; a++) {
+            uint32_t w = (uint32_t)in[a] | ((uint32_t)in[a + 1] << 8) | ((uint32_t)in[a + 2] << 16) | ((uint32_t)in[a + 3] << 24);
+            uint32_t h = zc_hash4(w);
+            uint64_t old = head[h]; head[h] = a + 1;
+            uint64_t d = old ? a + 1 - old : 0;
+            pdist4[a] = (uint16_t)(d > 32767 ? 0 : d);
+        }
+    }
+    const bool by_four = P.parser == ZC_PARSE_SLOW && !(P.nice < P.lazy || P.chain < 4 || P.nice < 4);   /* what the engine sends to k_lim + k_match */
     uint64_t chunks = n ? (n + chunk_size - 1) / chunk_size : 1;
     std::vector<uint8_t> out(n + n / 8 + chunks * 600 + 4096, 0);
     uint64_t obyte = 0;
@@ -98,6 +122,24 @@ static std::vector<uint8_t> emul_chunked(const uint8_t *in, uint64_t n, uint32_t
         std::vector<uint32_t> rf(g.len + 1), rq(g.len + 1);
         if (P.parser == ZC_PARSE_SLOW)
             for (uint32_t i = 0; i < g.len; i++) zc_match_pos(win, pd, g.dict_len + i, E, g.corner, P.nice, P.chain, &rf[i], &rq[i], P.max_dist);
+        if (by_four) {
+            /* k_reach + k_first3 + k_match: the same records from the four-byte chains and the two words per position */
+            const uint16_t *pdc4 = pdist4.data() + g.dstart, *pdc3 = pdist3e.data() + g.dstart;
+            auto pd4 = [&](uint32_t a) { return (uint32_t)pdc4[a]; };
+            auto pd3e = [&](uint32_t a) { return (uint32_t)pdc3[a]; };
+            for (uint32_t i = 0; i < g.len; i++) {
+                const uint32_t p = g.dict_len + i;
+                const uint32_t f3 = E - p >= ZC_MIN_MATCH ? zc_first3(win, pd3e, p, P.max_dist) : 0u;
+                const uint32_t lim = zc_lim_word(p, pd(p), zc_chain_reach(pd, p, P.chain), zc_chain_reach(pd, p, P.chain >> 2), P.max_dist, g.corner);
+                uint32_t f, q;
+                zc_match_pos4(win, pd4, p, E, P.nice, P.max_dist, lim, f3, &f, &q);
+                if (f != rf[i] || q != rq[i]) {
+                    fprintf(stderr, "four-byte chains differ at chunk %llu position %u: %08x %08x, hash chain %08x %08x (lim %08x f3 %08x)\n",
+                            (unsigned long long)c, i, f, q, rf[i], rq[i], lim, f3);
+                    exit(5);
+                }
+            }
+        }
         else if (P.parser == ZC_PARSE_RLE)
             for (uint32_t i = 0; i < g.len; i++) rf[i] = rq[i] = zc_rle_pos(win, g.dict_len + i, E);
         /* k_parse */

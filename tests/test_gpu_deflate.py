@@ -277,6 +277,71 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
+def test_search_along_four_byte_chains_is_exact_at_every_level():
+    """Chain budgets from 256 on (levels 7-9) search along the four-byte chains (k_reach, k_first3, k_match4), smaller
+    ones along the hash chains (k_match).  ZAMD_MATCH4_MIN_CHAIN=4 sends every budget the former way (read once per
+    process, hence the child process): levels 4-9, every strategy that searches, hash sizes, small windows, budgets
+    that are no power of two, ragged sizes, runs and periods up to MAX_DIST."""
+    import subprocess, sys
+    code = r"""
+import sys, random
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _oracle as O, zlib_amd
+eng = zlib_amd.Engine(0)
+rnd = random.Random(5)
+cases = []
+for kind in range(5):
+    cases.append((O.corpus((1 << 20) + 4321, kind, 17 + kind), 6, 0, 8, 1 << 19))
+for lvl in (4, 5, 6, 7, 8, 9):
+    cases.append((O.corpus(300000, 4, 21), lvl, 0, 8, 65536))
+for strat in (1, 4):
+    cases.append((O.corpus(700001, 3, 22), 6, strat, 8, 1 << 18))
+    cases.append((O.corpus(150000, 2, 23), 9, strat, 8, 65536))
+for mem in (1, 2, 4, 7, 9):
+    cases.append((O.corpus(400000, 4, 24), 6, 0, mem, 131072))
+for n in (0, 1, 2, 3, 4, 5, 261, 262, 263, 32767, 32768, 32769, 65274, 65277, 65374, 65535, 65536, 65537, 98304 + 32600):
+    cases.append((O.corpus(n, 0, 25), 6, 0, 8, 65536))
+    cases.append((O.corpus(n, 4, 26), 4, 0, 8, 32768))
+cases.append((bytes(300000), 6, 0, 8, 65536))
+cases.append((bytes(rnd.choice(b"ab") for _ in range(150000)), 5, 0, 8, 65536))
+for per in (1, 2, 3, 4, 5, 258, 259, 300, 32505, 32506, 32507):
+    base = bytes(rnd.getrandbits(8) for _ in range(per))
+    cases.append(((base * (120000 // per + 2))[:120000], 6, 0, 8, 65536))
+for data, level, strategy, mem, chunk in cases:
+    out, _ = eng.deflate_chunks(data, level=level, strategy=strategy, mem_level=mem, chunk_size=chunk)
+    assert out == O.deflate_chunked(data, chunk, level, strategy, mem)[0], (len(data), level, strategy, mem, chunk)
+data = O.corpus(3 * 65536 + 1234, 4, 61) + O.corpus(100000, 0, 62)
+for level, tune in ((6, (4, 4, 16, 8)), (6, (8, 258, 258, 300)), (9, (32, 16, 100, 2000)), (5, (40, 300, 1000, 17)), (6, (8, 16, 128, 100)), (4, (4, 4, 4, 5))):
+    eng.tune(*tune)
+    out, _ = eng.deflate_chunks(data, level=level, chunk_size=65536)
+    eng.tune()
+    want = b""
+    nch = (len(data) + 65535) // 65536
+    for c in range(nch):
+        start = c * 65536
+        dl, ln = min(start, 32768), min(65536, len(data) - start)
+        want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, level, 0, 8, c == nch - 1, tune=tune)
+    assert out == want, (level, tune)
+data = O.corpus(400000, 0, 63) + O.corpus(100000, 3, 64)
+for wbits in (9, 10, 12, 14):
+    eng.window_bits(wbits)
+    out, _ = eng.deflate_chunks(data, level=6, chunk_size=65536)
+    eng.window_bits(15)
+    want = b""
+    nch = (len(data) + 65535) // 65536
+    for c in range(nch):
+        start = c * 65536
+        dl, ln = min(start, 1 << wbits), min(65536, len(data) - start)
+        want += O.deflate_chunk(data[start - dl:start + ln], dl, ln, 6, 0, 8, c == nch - 1, wbits=wbits)
+    assert out == want, wbits
+eng.close()
+print("ok")
+""" % (os.path.join(ROOT, "tests"), ROOT)
+    env = dict(os.environ, ZAMD_MATCH4_MIN_CHAIN="4")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("level,tune", [(6, (4, 64, 8, 128)), (5, (20, 258, 9, 3)), (8, (1, 16, 4, 2)), (6, (33, 1, 8, 2)), (6, (14, 2, 9, 1))])
 def test_tuned_parameters_outside_the_tables_shape(engine, level, tune):
     """nice_length below max_lazy, chain budgets whose quarter is zero, lazy limits below 3."""

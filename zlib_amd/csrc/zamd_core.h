@@ -313,6 +313,116 @@ ZC_HD void zc_match_pos(const Win &win, const Pd &pd, uint32_t p, uint32_t E, ui
     zc_match_result(s, max_chain, rec_full, rec_quarter);
 }
 
+/* ------------------------------------------------------------------ the same search along four-byte chains
+ * longest_match() examines every member of the hash chain (strings that share three bytes, give or take a hash
+ * collision), and a member costs a step whether it can improve the match or not.  What it returns can be had from
+ * far fewer steps:
+ *   - a candidate of length 4 or more shares four bytes with the string, so it is a member of the string's FOUR-BYTE
+ *     chain (strings with the same hash of four bytes, newest first: zc_hash4, links built like the hash chain's);
+ *   - if no such candidate is within reach, the result is the nearest candidate of length 3 — the nearest earlier
+ *     string with the same three bytes, found along a chain of its own (zc_hash3e: a hash that spreads three-byte
+ *     strings evenly, so that the nearest member is the match but for rare collisions) — or nothing;
+ *   - "within reach" is the chain budget (max_chain candidates, a quarter of it from good_match on, deflate.c:1185-1187)
+ *     and the distance limit (:1158-1159, 1284).  The budget counts hash-chain members, so it is turned into a
+ *     distance once per position: the distance of the string's max_chain-th (max_chain/4-th) predecessor in the hash
+ *     chain.  A candidate is within the budget iff it is no further away than that.
+ * The walk is over four-byte-chain members no further than min(budget distance, MAX_DIST - 1) and keeps
+ * longest_match's rules (strictly longer wins, the first candidate of nice length ends it).  The hash-chain head alone
+ * may lie at exactly MAX_DIST (:1660, 1766); nothing lies behind it then, and it is the only candidate.
+ *
+ * Per position two words say all this (k_reach and k_first3 write them, k_match reads them):
+ *   lim   bits 0-14: the largest distance a candidate may have (full budget); bit 15: the hash-chain head lies at
+ *         exactly MAX_DIST and is admissible; bits 16-31: the largest distance within a quarter of the budget
+ *   f3    distance of the nearest earlier string with the same three bytes, 0 = none within MAX_DIST */
+ZC_HD uint32_t zc_hash4(uint32_t w) { return (w * 0x9E3779B1u) >> 17; }
+ZC_HD uint32_t zc_hash3e(uint32_t w) { return ((w & 0x00ffffffu) * 0x9E3779B1u) >> 17; }
+
+/* pd3e(a) = distance to the previous string with a's zc_hash3e, 0 = none within 32767 */
+template <class Win, class Pd>
+ZC_HD uint32_t zc_first3(const Win &win, const Pd &pd3e, uint32_t p, uint32_t max_dist)
+{
+    const uint32_t scan3 = win.load4(p) & 0x00ffffffu;
+    uint32_t cur = p;
+    for (;;) {
+        const uint32_t d = pd3e(cur);
+        if (d == 0 || d > cur) return 0;
+        cur -= d;
+        if (p - cur > max_dist) return 0;
+        if ((win.load4(cur) & 0x00ffffffu) == scan3) return p - cur;
+    }
+}
+
+/* Distance from p to its steps-th predecessor in the hash chain, 0xffff when the chain ends before it or the distance
+ * exceeds 32767 (k_reach gets the same number by pointer jumping). */
+template <class Pd>
+ZC_HD uint32_t zc_chain_reach(const Pd &pd, uint32_t p, uint32_t steps)
+{
+    uint32_t cur = p;
+    for (uint32_t k = 0; k < steps; k++) {
+        const uint32_t d = pd(cur);
+        if (d == 0 || d > cur) return 0xffffu;
+        cur -= d;
+        if (p - cur > 32767u) return 0xffffu;
+    }
+    return p - cur;
+}
+
+/* head_dist: the position's own hash-chain link (0 = none) */
+ZC_HD uint32_t zc_lim_word(uint32_t p, uint32_t head_dist, uint32_t reach_full, uint32_t reach_quarter, uint32_t max_dist, uint32_t corner)
+{
+    uint32_t wf = reach_full < max_dist - 1u ? reach_full : max_dist - 1u;      /* later candidates need cur > limit, :1284 */
+    const uint32_t nil = p ? p - 1u : 0u;                                      /* a-coordinate 0 is NIL */
+    if (wf > nil) wf = nil;
+    const uint32_t wq = reach_quarter < wf ? reach_quarter : wf;
+    /* hash_head at exactly MAX_DIST (:1660, 1766), unless it is window index 0 or has slid onto it in tail mode */
+    const uint32_t lone = (head_dist == max_dist && p > max_dist && p != corner) ? 0x8000u : 0u;
+    return wf | lone | (wq << 16);
+}
+
+/* longest_match for position p from its two words and the four-byte chain (pd4(a) = distance to the previous string
+ * with a's four-byte hash, 0 = none within 32767).  Same result words as zc_match_pos. */
+template <class Win, class Pd4>
+ZC_HD void zc_match_pos4(const Win &win, const Pd4 &pd4, uint32_t p, uint32_t E, uint32_t nice_match, uint32_t max_dist, uint32_t lim, uint32_t f3,
+                         uint32_t *rec_full, uint32_t *rec_quarter)
+{
+    *rec_full = 0; *rec_quarter = 0;
+    const uint32_t look = E - p, d3 = f3 & 0x7fffu;
+    if (look < ZC_MIN_MATCH || d3 == 0) return;
+    uint32_t wf = lim & 0x7fffu, wq = lim >> 16;
+    const uint32_t cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH, nice = nice_match < look ? nice_match : look;
+    uint32_t best, full = 0, qrec = 0, cur, d;
+    if (lim & 0x8000u) {
+        /* the hash-chain head at MAX_DIST is the only candidate there is; it is measured in full if its three bytes match */
+        if (d3 != max_dist) return;
+        best = ZC_MIN_MATCH - 1u; cur = p; d = max_dist; wf = max_dist; wq = max_dist;
+    } else {
+        if (d3 > wf) return;
+        full = ZC_MIN_MATCH | (d3 << 16); qrec = d3 <= wq ? full : 0u;
+        best = ZC_MIN_MATCH; cur = p; d = pd4(p);
+        if (cap == ZC_MIN_MATCH) d = 0;
+    }
+    while (d != 0 && (p - cur) + d <= wf) {
+        cur -= d;
+        if (((win.load4(cur + best - 2u) ^ win.load4(p + best - 2u)) & 0x00ffffffu) == 0) {    /* the peek of k_match */
+            uint32_t len = 0;
+            while (len < cap) {
+                const uint32_t x = win.load4(cur + len) ^ win.load4(p + len);
+                if (x) { len += zc_ctz32(x) >> 3; break; }
+                len += 4;
+            }
+            if (len > cap) len = cap;
+            if (len > best) {
+                best = len; full = len | ((p - cur) << 16);
+                if (p - cur <= wq) qrec = full;
+                if (len >= nice) break;                /* :1276 */
+            }
+        }
+        if (lim & 0x8000u) break;
+        d = pd4(cur);
+    }
+    *rec_full = full; *rec_quarter = qrec;
+}
+
 /* Z_RLE (deflate.c:1884-1898): run of bytes equal to the previous byte. */
 template <class Win>
 ZC_HD uint32_t zc_rle_pos(const Win &win, uint32_t p, uint32_t E)

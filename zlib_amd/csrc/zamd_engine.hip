@@ -56,7 +56,7 @@ struct ZkJob {
     uint64_t last_chunk;          /* absolute number of the call's last chunk: the one P.tail applies to */
     uint32_t prime_bits, prime_val;  /* deflatePrime bits in front of the call's first chunk */
     ZcParams P;
-    uint16_t *pdist; uint64_t pdist_base, pdist_len;
+    uint16_t *pdist; uint64_t pdist_base, pdist_len;   /* chain links: of the hash chains; where k_match4 searches, of the four-byte chains once k_reach has read those */
     uint2 *rec; uint64_t rec_base;
     uint32_t *sym;
     uint32_t *hop; uint32_t *arr; uint32_t *nhop;
@@ -133,8 +133,14 @@ __device__ inline uint32_t zk_wave_scan_max(uint32_t v)
     s = max(s, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, true));
     return s;
 }
-__global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
+/* mode 0: the hash chains of the reference (UPDATE_HASH with the stream's hash_bits).  The same build serves two chains
+ * of this engine's own, each 15 bits wide and one pass, each taking the previous one's place in J.pdist once its reader
+ * has run: mode 2, strings with the same zc_hash3e of their three bytes (k_first3 finds the nearest three-byte match
+ * along them), and mode 1, the FOUR-BYTE chains (zc_hash4 of the first four bytes) that k_match walks. */
+enum { ZK_CHAIN_REF = 0, ZK_CHAIN_FOUR = 1, ZK_CHAIN_THREE = 2 };
+__global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J, int mode)
 {
+    const bool four = mode == ZK_CHAIN_FOUR;
     __shared__ uint32_t head[32768];
     __shared__ uint16_t s_hash[ZK_CHAIN_ROUND];       /* hash of every position of the round, 0xffff = not part of this pass */
     __shared__ uint16_t s_link[ZK_CHAIN_ROUND];
@@ -147,14 +153,15 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     const uint64_t c = J.chunk0 + blockIdx.x;
     const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, c, J.finish, J.head, J.P.wsize);
     const uint32_t E = g.dict_len + g.len;
-    /* positions with three bytes available in the whole input */
+    /* positions with three (four) bytes available in the whole input */
     uint64_t avail = J.n - g.dstart;
     uint32_t Ex = E;
-    if ((uint64_t)E + 2 > avail) Ex = avail >= 2 ? (uint32_t)(avail - 2) : 0;
+    const uint32_t more = four ? 3u : 2u;
+    if ((uint64_t)E + more > avail) Ex = avail >= more ? (uint32_t)(avail - more) : 0;
     const uint32_t out_from = blockIdx.x == 0 ? 0u : g.dict_len;
     const uint8_t *src = J.in + g.dstart;
     uint16_t *pd = J.pdist + (g.dstart - J.pdist_base);
-    const uint32_t passes = J.P.hash_bits > 15 ? (1u << (J.P.hash_bits - 15)) : 1u;
+    const uint32_t passes = (mode == ZK_CHAIN_REF && J.P.hash_bits > 15) ? (1u << (J.P.hash_bits - 15)) : 1u;
     /* the two aligned words that hold bytes a..a+2, fetched one round ahead, without a branch so that nothing waits for
      * them before the next round uses them.  A dictionary of any length in front of the first chunk leaves a-coordinate 0
      * at any address: `mis` is its offset from a dword boundary.  Positions past the last string read the last string's
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
     auto fetch = [&](uint32_t a, uint32_t &w0, uint32_t &w1) {
         const uint32_t x = (a < Ex ? a : Ex - 1u) + mis, al = x & ~3u;
         w0 = *(const uint32_t *)(srca + al);
-        w1 = *(const uint32_t *)(srca + al + ((x & 2u) << 1));
+        w1 = *(const uint32_t *)(srca + al + (four ? ((x & 3u) ? 4u : 0u) : ((x & 2u) << 1)));
     };
     for (uint32_t pass = 0; pass < passes; pass++) {
         for (uint32_t i = tid; i < 32768; i += ZK_CHAIN_THREADS) head[i] = 0;
@@ -190,7 +197,8 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
                 hv[u] = 0xffffu; rank[u] = 0;
                 if (a < Ex) {
                     uint32_t b3 = __builtin_amdgcn_alignbyte(w1[u], w0[u], (a + mis) & 3u);
-                    uint32_t h = zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
+                    uint32_t h = four ? zc_hash4(b3) : mode == ZK_CHAIN_THREE ? zc_hash3e(b3) :
+                                 zc_hash3(b3 & 0xffu, (b3 >> 8) & 0xffu, (b3 >> 16) & 0xffu, J.P.hash_shift, J.P.hash_mask);
                     if ((h >> 15) == pass) hv[u] = h & 32767u;
                 }
                 const uint32_t hp = __shfl_up(hv[u], 1), hn = __shfl_down(hv[u], 1);
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(ZK_CHAIN_THREADS) void k_chain(ZkJob J)
         }
         __syncthreads();
     }
-    /* strings without three bytes of input are never inserted */
+    /* strings without three (four) bytes of input are never inserted */
     for (uint32_t a = Ex + tid; a < E; a += ZK_CHAIN_THREADS) if (a >= out_from) pd[a] = 0;
 }
 
@@ -328,11 +336,11 @@ __device__ inline uint4 zk_links_none(uint4 q)
     }
     return make_uint4(t[0], t[1], t[2], t[3]);
 }
-__device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64_t a0, uint16_t *s_pd, uint32_t count, uint32_t tid)
+__device__ inline void zk_load_links(const ZkJob &J, const uint16_t *links, const ZcChunkGeom &g, int64_t a0, uint16_t *s_pd, uint32_t count, uint32_t tid)
 {
     if (a0 >= 0 && g.dstart + (uint64_t)a0 - J.pdist_base + count <= J.pdist_len && count == 6u * 8u * ZK_MATCH_THREADS) {
         /* all links exist: six loads per thread in flight together */
-        const uint4 *src = (const uint4 *)(J.pdist + (g.dstart + (uint64_t)a0 - J.pdist_base));
+        const uint4 *src = (const uint4 *)(links + (g.dstart + (uint64_t)a0 - J.pdist_base));
         uint4 q[6];
 #pragma unroll
         for (uint32_t k = 0; k < 6; k++) q[k] = src[tid + k * ZK_MATCH_THREADS];
@@ -345,7 +353,7 @@ __device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64
         uint4 q = make_uint4(0, 0, 0, 0);
         if (a >= 0) {
             uint64_t idx = g.dstart + (uint64_t)a - J.pdist_base;
-            if (idx + 8 <= J.pdist_len) q = *(const uint4 *)(J.pdist + idx);
+            if (idx + 8 <= J.pdist_len) q = *(const uint4 *)(links + idx);
         }
         uint32_t t[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
@@ -354,6 +362,143 @@ __device__ inline void zk_load_links(const ZkJob &J, const ZcChunkGeom &g, int64
             if ((t[k] >> 16) == 0) t[k] |= 0xffff0000u;
         }
         ((uint4 *)s_pd)[v] = make_uint4(t[0], t[1], t[2], t[3]);
+    }
+}
+
+/* ------------------------------------------------------------------ k_first3, k_reach
+ * What k_match needs to know about a position before it walks the four-byte chain (zamd_core.h, "the same search
+ * along four-byte chains"): the nearest earlier string with the same three bytes, and how far back the chain budget
+ * reaches — the distance to the position's max_chain-th (and max_chain/4-th) predecessor in the hash chain.
+ *
+ * k_first3: one workgroup per tile of 16 Ki positions, window bytes and the links of the exact three-byte chains
+ * (k_chain in mode ZK_CHAIN_THREE) of tile + 32 KiB halo in LDS as in k_match.  The nearest member of that chain is the
+ * match unless two different strings share a hash value; then the walk goes on, a step or two. */
+__global__ __launch_bounds__(ZK_MATCH_THREADS) void k_first3(ZkJob J, uint32_t tiles_per_chunk)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_lds[ZK_LDS_BYTES / 4];
+    uint32_t *s_win = s_lds;
+    uint16_t *s_pd = (uint16_t *)(s_lds + ZK_PD_OFF / 4);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
+    if ((uint64_t)tile * ZK_TILE >= g.len) return;
+    const uint32_t E = g.dict_len + g.len;
+    const uint32_t t0 = g.dict_len + tile * ZK_TILE;
+    const uint32_t tlen = (E - t0) < ZK_TILE ? (E - t0) : ZK_TILE;
+    const int64_t a0 = (int64_t)t0 - (int64_t)ZK_HALO;
+    zk_load_window(J, g, a0, s_win, ZK_WIN_BYTES, tid);
+    zk_load_links(J, J.pdist, g, a0, s_pd, ZK_HALO + ZK_TILE, tid);
+    __syncthreads();
+    LdsWin win; win.w = s_win; win.a0 = (uint32_t)a0;
+    LdsPd pd; pd.pd = s_pd; pd.a0 = (uint32_t)a0;
+    /* the word waits where the symbols will be: those are written once k_match is through */
+    uint32_t *const f3w = J.sym + (uint64_t)lc * J.P.chunk_size + tile * ZK_TILE;
+#pragma unroll 1
+    for (uint32_t i = tid; i < tlen; i += ZK_MATCH_THREADS)
+        f3w[i] = E - (t0 + i) >= ZC_MIN_MATCH ? zc_first3(win, pd, t0 + i, J.P.max_dist) : 0u;
+}
+
+/* k_reach: the k-th predecessor in the hash chain by pointer jumping.  One workgroup per 32 Ki positions; the image of
+ * the hash-chain links of those and the 32 Ki in front of them is 65 536 16-bit entries, so that every 16-bit index
+ * lies inside it and the gathers need no bounds.  Entry x holds the distance from x to its 2^r-th predecessor after
+ * round r; round r + 1 adds the entry found that far back: A[x] += A[x - A[x]], for every entry of the image, in place
+ * (all reads of a round are made before a barrier, all writes behind it), two entries to a register and the sums and
+ * differences two at a time.  A distance of 0x8000 or more stands for "none within 32767" — the loader writes 0xffff
+ * for the end of a chain, the sums saturate, so such an entry never comes back below 0x8000 — and entry 0 is none by
+ * decree: x - A[x] saturates at 0, the index that a link out of the image's front becomes (nothing the tile can use
+ * lies that far back).  A tile position collects the rounds that are bits of its budgets. */
+typedef unsigned short zk_u16x2 __attribute__((ext_vector_type(2)));
+#define ZK_REACH_TILE 32768u
+#define ZK_REACH_NP   ((ZK_HALO + ZK_REACH_TILE) / 2u / ZK_MATCH_THREADS)       /* pairs of entries per thread: 32 */
+__device__ inline zk_u16x2 zk_pair(uint32_t w) { zk_u16x2 v; v.x = (unsigned short)w; v.y = (unsigned short)(w >> 16); return v; }
+__device__ inline uint32_t zk_word(zk_u16x2 v) { return (uint32_t)v.x | ((uint32_t)v.y << 16); }
+__device__ inline zk_u16x2 zk_gather(const uint16_t *img, zk_u16x2 idx) { zk_u16x2 v; v.x = img[idx.x]; v.y = img[idx.y]; return v; }
+__global__ __launch_bounds__(ZK_MATCH_THREADS) void k_reach(ZkJob J, uint32_t tiles_per_chunk)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_img[(ZK_HALO + ZK_REACH_TILE) / 2u];
+    uint16_t *const img = (uint16_t *)s_img;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
+    if ((uint64_t)tile * ZK_REACH_TILE >= g.len) return;
+    const uint32_t E = g.dict_len + g.len;
+    const uint32_t t0 = g.dict_len + tile * ZK_REACH_TILE;
+    const uint32_t tlen = (E - t0) < ZK_REACH_TILE ? (E - t0) : ZK_REACH_TILE;
+    const int64_t a0 = (int64_t)t0 - (int64_t)ZK_HALO;
+    {
+        const uint64_t i0 = g.dstart + (uint64_t)a0 - J.pdist_base;
+        if (a0 >= 0 && i0 + (ZK_HALO + ZK_REACH_TILE) <= J.pdist_len) {
+            /* all links exist: eight loads per thread in flight together */
+            const uint4 *src = (const uint4 *)(J.pdist + i0);
+            uint4 q[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) q[k] = src[tid + k * ZK_MATCH_THREADS];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) ((uint4 *)s_img)[tid + k * ZK_MATCH_THREADS] = zk_links_none(q[k]);
+        } else zk_load_links(J, J.pdist, g, a0, img, ZK_HALO + ZK_REACH_TILE, tid);
+    }
+    __syncthreads();
+    if (tid == 0) img[0] = ZK_PD_NONE;
+    __syncthreads();
+    const uint32_t max_chain = J.P.chain, qchain = max_chain >> 2;
+    /* R: where the walk of `budget` steps stands, as an index into the image (0: it has left the picture) */
+    zk_u16x2 RF[ZK_REACH_NP / 2], RQ[ZK_REACH_NP / 2];
+#pragma unroll
+    for (uint32_t j = 0; j < ZK_REACH_NP / 2; j++) {
+        const uint32_t x = 2u * ((j + ZK_REACH_NP / 2) * ZK_MATCH_THREADS + tid);
+        RF[j] = zk_pair(x | ((x + 1u) << 16)); RQ[j] = RF[j];
+    }
+    const uint32_t top = 31u - (uint32_t)__clz((int)max_chain);
+    for (uint32_t r = 0; r <= top; r++) {
+        if ((max_chain >> r) & 1u) {
+#pragma unroll
+            for (uint32_t j = 0; j < ZK_REACH_NP / 2; j++) RF[j] = __builtin_elementwise_sub_sat(RF[j], zk_gather(img, RF[j]));
+        }
+        if ((qchain >> r) & 1u) {
+#pragma unroll
+            for (uint32_t j = 0; j < ZK_REACH_NP / 2; j++) RQ[j] = __builtin_elementwise_sub_sat(RQ[j], zk_gather(img, RQ[j]));
+        }
+        if (r == top) break;
+        uint32_t nv[ZK_REACH_NP];
+#pragma unroll
+        for (uint32_t j0 = 0; j0 < ZK_REACH_NP; j0 += 8) {
+            uint32_t own[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) own[u] = s_img[(j0 + u) * ZK_MATCH_THREADS + tid];
+#pragma unroll
+            for (uint32_t u = 0; u < 8; u++) {
+                const uint32_t x = 2u * ((j0 + u) * ZK_MATCH_THREADS + tid);
+                const zk_u16x2 o = zk_pair(own[u]);
+                const zk_u16x2 idx = __builtin_elementwise_sub_sat(zk_pair(x | ((x + 1u) << 16)), o);
+                nv[j0 + u] = zk_word(__builtin_elementwise_add_sat(o, zk_gather(img, idx)));
+            }
+            asm volatile("" ::: "memory");
+        }
+        if (tid == 0) nv[0] |= 0xffffu;               /* entry 0 stays "none" */
+        ZK_LDS_BARRIER();
+#pragma unroll
+        for (uint32_t j = 0; j < ZK_REACH_NP; j++) s_img[j * ZK_MATCH_THREADS + tid] = nv[j];
+        ZK_LDS_BARRIER();
+    }
+    /* the word waits where the hop words will be: those are written once k_match is through */
+    uint32_t *const limw = J.hop + (uint64_t)lc * J.P.chunk_size + tile * ZK_REACH_TILE;
+    const uint16_t *const link = J.pdist + (g.dstart + t0 - J.pdist_base);      /* the position's own link, from memory again */
+#pragma unroll
+    for (uint32_t j = 0; j < ZK_REACH_NP / 2; j++) {
+        const uint32_t x = 2u * ((j + ZK_REACH_NP / 2) * ZK_MATCH_THREADS + tid), i = x - ZK_HALO;
+        if (i >= tlen) continue;
+        const uint32_t rf[2] = {RF[j].x, RF[j].y}, rq[2] = {RQ[j].x, RQ[j].y};
+        uint32_t w[2] = {0, 0};
+#pragma unroll
+        for (uint32_t e = 0; e < 2; e++) {
+            if (i + e >= tlen) break;
+            uint32_t df = rf[e] ? x + e - rf[e] : 0xffffu, dq = rq[e] ? x + e - rq[e] : 0xffffu;
+            if (df > 32767u) df = 0xffffu;
+            if (dq > 32767u) dq = 0xffffu;
+            w[e] = zc_lim_word(t0 + i + e, link[i + e], df, dq, J.P.max_dist, g.corner);
+        }
+        if (i + 1u < tlen) *(uint2 *)(limw + i) = make_uint2(w[0], w[1]);
+        else limw[i] = w[0];
     }
 }
 
@@ -374,7 +519,7 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
     const uint32_t tlen = (E - t0) < ZK_TILE ? (E - t0) : ZK_TILE;
     const int64_t a0 = (int64_t)t0 - (int64_t)ZK_HALO;      /* a-coordinate of LDS byte 0 */
     zk_load_window(J, g, a0, s_win, ZK_WIN_BYTES, tid);
-    if (!rle) zk_load_links(J, g, a0, s_pd, ZK_HALO + ZK_TILE, tid);
+    if (!rle) zk_load_links(J, J.pdist, g, a0, s_pd, ZK_HALO + ZK_TILE, tid);
     if (tid == 0) s_next = 0;
     __syncthreads();
     LdsWin win; win.w = s_win; win.a0 = (uint32_t)a0;
@@ -712,6 +857,242 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match(ZkJob J, uint32_t ti
             uint32_t rq = qb == 0 ? 0u : (k > qb ? qrec : full_now);
             rec[pout] = make_uint2(full_now, rq);
         }
+        walking = wm | parked;                /* parked walks are still owned by the lane */
+    }
+}
+
+/* ------------------------------------------------------------------ k_match4
+ * The search of k_match along the four-byte chains, for large chain budgets (levels 8 and 9): see "the same search
+ * along four-byte chains" in zamd_core.h.  Same tile, same persistent lanes, same records. */
+__global__ __launch_bounds__(ZK_MATCH_THREADS) void k_match4(ZkJob J, uint32_t tiles_per_chunk)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_lds[ZK_LDS_BYTES / 4];
+    __shared__ __attribute__((aligned(16))) uint2 s_tick[ZK_MATCH_THREADS];       /* per wavefront: the two words of the 64 positions of its ticket */
+    __shared__ uint32_t s_next;
+    uint32_t *s_win = s_lds;
+    uint16_t *s_pd = (uint16_t *)(s_lds + ZK_PD_OFF / 4);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lc = blockIdx.x / tiles_per_chunk, tile = blockIdx.x % tiles_per_chunk;
+    const ZcChunkGeom g = zc_geom(J.n, J.P.chunk_size, J.chunk0 + lc, J.finish, J.head, J.P.wsize);
+    if ((uint64_t)tile * ZK_TILE >= g.len) return;
+    const uint32_t E = g.dict_len + g.len;
+    const uint32_t t0 = g.dict_len + tile * ZK_TILE;
+    const uint32_t tlen = (E - t0) < ZK_TILE ? (E - t0) : ZK_TILE;
+    const int64_t a0 = (int64_t)t0 - (int64_t)ZK_HALO;      /* a-coordinate of LDS byte 0 */
+    zk_load_window(J, g, a0, s_win, ZK_WIN_BYTES, tid);
+    zk_load_links(J, J.pdist, g, a0, s_pd, ZK_HALO + ZK_TILE, tid);
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    LdsWin win; win.w = s_win; win.a0 = (uint32_t)a0;
+    uint2 *rec = J.rec + (g.dstart + t0 - J.rec_base);
+    const uint32_t lane = tid & 63u;
+    /* Persistent lanes.  A lane walks the four-byte chain of one position (zc_match_pos4 in zamd_core.h says what the
+     * walk computes); a lane whose walk is over draws the next unclaimed position of the tile once enough lanes of
+     * the wavefront are idle, so chains of very different length do not leave the wavefront waiting on its slowest
+     * lane.  The per-candidate step is written as straight-line integer arithmetic, because the scalar unit a CU's
+     * four SIMDs share is what nested predicates would saturate.  Candidates that pass the 3-byte peek are parked and
+     * compared in full, together, at the next service point.
+     * Positions are handed out in tickets of 64 to a wavefront.  The two words k_reach and k_first3 left for a ticket's positions are
+     * fetched when the ticket is drawn, one ticket ahead of its use, and wait in registers; when the wavefront starts
+     * on the ticket they go to the wavefront's slice of s_tick, where the lane that takes a position finds them. */
+    const uint32_t nice_match = J.P.nice, max_dist = J.P.max_dist;
+    const uint32_t la0 = (uint32_t)a0;
+    const uint32_t *const limw = J.hop + (uint64_t)lc * J.P.chunk_size + tile * ZK_TILE;
+    const uint32_t *const f3w = J.sym + (uint64_t)lc * J.P.chunk_size + tile * ZK_TILE;
+    uint2 *const tick = s_tick + (tid - lane);
+    uint32_t p = t0, cur = t0, best = ZC_MIN_MATCH, full = 0, qrec = 0, scan3 = 0, cap = 0, nice = 0, wf = 0, wq = 0;
+    auto set_scan = [&](uint32_t b) { scan3 = win.load4(p + b - 2u) & 0x00ffffffu; };
+    int32_t walking = 0, parked = 0;          /* sign masks: -1 / 0 */
+    uint32_t wcur = 0, wend = 0;              /* the ticket in use: unclaimed positions [wcur, wend) */
+    uint32_t tbase = 0;                       /* first position of the ticket in use */
+    uint32_t nbase;                           /* first position of the ticket drawn ahead (>= tlen: there is none) */
+    uint2 nlim = make_uint2(0, 0);            /* this lane's share of its two words */
+    auto draw = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_next, 64u);
+        nbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t at = nbase + lane < tlen ? nbase + lane : tlen - 1u;  /* no branch: nothing waits for the loads here */
+        nlim.x = limw[at]; nlim.y = f3w[at];
+    };
+    draw();
+    for (;;) {
+        /* ---- full comparisons of parked candidates */
+        if (parked < 0) {
+            /* the first 16 bytes of both strings (most comparisons end there), then 32 bytes a round trip */
+            uint32_t len, dnext;
+            {
+                const uint32_t oc = cur - la0, op = p - la0, ic = oc >> 2, ip = op >> 2;
+                dnext = s_pd[oc];               /* the link, fetched in the same round trip; "none" is 0xffff */
+                const uint32_t c0 = s_win[ic], c1 = s_win[ic + 1], c2 = s_win[ic + 2], c3 = s_win[ic + 3], c4 = s_win[ic + 4];
+                const uint32_t q0 = s_win[ip], q1 = s_win[ip + 1], q2 = s_win[ip + 2], q3 = s_win[ip + 3], q4 = s_win[ip + 4];
+                const uint32_t x0 = __builtin_amdgcn_alignbyte(c1, c0, oc) ^ __builtin_amdgcn_alignbyte(q1, q0, op);
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(c2, c1, oc) ^ __builtin_amdgcn_alignbyte(q2, q1, op);
+                const uint32_t x2 = __builtin_amdgcn_alignbyte(c3, c2, oc) ^ __builtin_amdgcn_alignbyte(q3, q2, op);
+                const uint32_t x3 = __builtin_amdgcn_alignbyte(c4, c3, oc) ^ __builtin_amdgcn_alignbyte(q4, q3, op);
+                len = x0 ? zc_ctz32(x0) >> 3 : x1 ? 4u + (zc_ctz32(x1) >> 3) : x2 ? 8u + (zc_ctz32(x2) >> 3) : x3 ? 12u + (zc_ctz32(x3) >> 3) : 16u;
+            }
+            if (len == 16u) {
+                /* long matches (runs, repeated records): a wavefront stays in this loop as long as its longest comparison does */
+                while (len < cap) {
+                    const uint32_t oc = cur + len - la0, op = p + len - la0, ic = oc >> 2, ip = op >> 2;
+                    uint32_t c[9], q[9], x[8];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) { c[k] = s_win[ic + k]; q[k] = s_win[ip + k]; }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[k] = __builtin_amdgcn_alignbyte(c[k + 1], c[k], oc) ^ __builtin_amdgcn_alignbyte(q[k + 1], q[k], op);
+                    uint32_t n = 32u;
+#pragma unroll
+                    for (int k = 7; k >= 0; k--) n = x[k] ? 4u * (uint32_t)k + (zc_ctz32(x[k]) >> 3) : n;
+                    len += n;
+                    if (n < 32u) break;
+                }
+            }
+            if (len > cap) len = cap;
+            bool fin = false;
+            const uint32_t bd = p - cur;
+            if (len > best) {
+                best = len; full = len | (bd << 16);
+                if (bd <= wq) qrec = full;      /* within the quarter budget as well */
+                if (len >= nice) fin = true;    /* deflate.c:1276 */
+                else set_scan(len);
+            }
+            if (!fin) {
+                if (bd + dnext > wf) fin = true;          /* the next member is out of reach (budget, MAX_DIST, NIL) or there is none */
+                else cur -= dnext;
+            }
+            parked = 0; walking = -1;
+            if (fin) { rec[p - t0] = make_uint2(full, qrec); walking = 0; }
+        }
+        /* ---- refill idle lanes from the wavefront's ticket */
+        for (int pass = 0; pass < 2; pass++) {
+            unsigned long long idle = __ballot(walking == 0);
+            if (idle == 0ull) break;
+            if (wcur == wend) {
+                if (nbase >= tlen) break;                 /* the tile's positions are all claimed */
+                /* the ticket drawn ahead is the ticket in use from here on: its words go where the lanes find them */
+                tbase = nbase; wcur = nbase; wend = nbase + 64u < tlen ? nbase + 64u : tlen;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                tick[lane] = nlim;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                draw();
+            }
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            const uint32_t take = (uint32_t)__popcll(idle) < wend - wcur ? (uint32_t)__popcll(idle) : wend - wcur;
+            if (walking == 0 && rank < take) {
+                const uint32_t idx = wcur + rank, pp = t0 + idx, look = E - pp;
+                const uint2 L = tick[idx - tbase];
+                const uint32_t d3 = L.y & 0x7fffu;
+                uint32_t f = 0, q = 0, d4 = 0, b0 = ZC_MIN_MATCH, nwf = L.x & 0x7fffu, nwq = L.x >> 16;
+                bool walk = false;
+                if (look >= ZC_MIN_MATCH && d3 != 0u) {
+                    if (L.x & 0x8000u) {
+                        /* the hash-chain head at exactly MAX_DIST is the only candidate there is: it is measured in full if its
+                         * three bytes match (the first step's peek then parks it), and nothing lies within reach behind it */
+                        if (d3 == max_dist) { walk = true; d4 = max_dist; b0 = ZC_MIN_MATCH - 1u; nwf = 0; nwq = 0xffffu; }
+                    } else if (d3 <= nwf) {
+                        f = ZC_MIN_MATCH | (d3 << 16); q = d3 <= nwq ? f : 0u;
+                        d4 = s_pd[pp - la0];
+                        walk = look > ZC_MIN_MATCH && d4 <= nwf;
+                    }
+                }
+                if (walk) {
+                    p = pp; cur = pp - d4; best = b0; full = f; qrec = q; wf = nwf; wq = nwq;
+                    cap = look < ZC_MAX_MATCH ? look : ZC_MAX_MATCH; nice = nice_match < look ? nice_match : look;
+                    set_scan(b0);
+                    walking = -1;
+                } else rec[idx] = make_uint2(f, q);
+            }
+            wcur += take;
+        }
+        if (__ballot(walking < 0) == 0ull) { if (wcur == wend && nbase >= tlen) break; continue; }
+        /* ---- candidate steps until a quarter of the lanes need service */
+        const uint32_t pout = p - t0;
+        /* the loop runs on c = candidate + (best - 2) - la0, the LDS byte offset of the candidate's bytes best-2..,
+         * so that neither the peek address nor the link address nor the reach test needs an addition of its own */
+        const uint32_t peek_off = (best - 2u) - la0;
+        uint32_t c = cur + peek_off;
+        const int32_t plim = (int32_t)(p - wf - 1u + peek_off);      /* the next candidate c' is in reach while plim - c' < 0 */
+        /* a walk that has stopped is masked off for the rest of the round: c and the last peek result stay as the
+         * stopping step left them */
+        int32_t wm = walking;
+        uint32_t xlast = 1u;
+#ifdef ZK_MATCH_ASM
+        /* The round by hand: a lane that stops is taken out of EXEC by the comparison that stops it — the peek that
+         * matched (the lane stays on that candidate), or the reach test on the next member — and EXEC is restored
+         * after the round, so a step needs no mask register and no scalar instruction: 8 vector + 2 LDS instructions.
+         * The reach test runs on r = plim - c, which the step's own sum carries to the next step.  (v50-v54 and
+         * s90-s95 are named outright because ds_read2_b32 wants a register PAIR whose halves the next instruction
+         * names one by one; the clobber list keeps the compiler off them.) */
+        {
+            const uint32_t wbase = (uint32_t)(uintptr_t)s_win;
+            uint32_t ca = c + wbase;
+            const uint32_t l0 = (uint32_t)(uintptr_t)s_pd - 2u * (best - 2u) - 2u * wbase;
+            int32_t r = plim - (int32_t)c;
+#define ZK_STEP \
+            "v_and_b32 v50, -4, %[c]\n\t" \
+            "ds_read2_b32 v[52:53], v50 offset1:1\n\t" \
+            "v_lshl_add_u32 v51, %[c], 1, %[l0]\n\t" \
+            "ds_read_u16 v54, v51\n\t" \
+            "s_waitcnt lgkmcnt(1)\n\t" \
+            "v_alignbyte_b32 v52, v53, v52, %[c]\n\t" \
+            "v_bitop3_b32 %[x], v52, %[scan], %[mask] bitop3:0x6c\n\t" \
+            "v_cmpx_ne_u32_e32 vcc, 0, %[x]\n\t" \
+            "s_waitcnt lgkmcnt(0)\n\t" \
+            "v_add_u32 %[r], %[r], v54\n\t" \
+            "v_cmpx_gt_i32_e32 vcc, 0, %[r]\n\t" \
+            "v_sub_u32 %[c], %[c], v54\n\t"
+            asm volatile(
+            "s_mov_b64 s[90:91], exec\n\t"
+            "v_cmp_gt_i32_e32 vcc, 0, %[wm]\n\t"
+            "s_and_b64 exec, exec, vcc\n\t"
+            "s_mov_b32 s92, %[rounds]\n\t"
+            "1:\n\t"
+            ZK_STEP ZK_STEP ZK_STEP ZK_STEP
+            "s_bcnt1_i32_b64 s93, exec\n\t"
+            "s_cmp_le_u32 s93, %[keep]\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "s_add_i32 s92, s92, -1\n\t"
+            "s_cmp_lg_u32 s92, 0\n\t"
+            "s_cbranch_scc1 1b\n\t"
+            "2:\n\t"
+            "s_mov_b64 s[94:95], exec\n\t"
+            "s_mov_b64 exec, s[90:91]\n\t"
+            "v_mov_b32 %[wm], 0\n\t"
+            "s_mov_b64 exec, s[94:95]\n\t"
+            "v_mov_b32 %[wm], -1\n\t"
+            "s_mov_b64 exec, s[90:91]\n\t"
+            : [c] "+v"(ca), [x] "+v"(xlast), [r] "+v"(r), [wm] "+v"(wm)
+            : [l0] "v"(l0), [scan] "v"(scan3), [mask] "s"(0x00ffffffu), [keep] "n"(64 - ZK_MATCH_THRESH), [rounds] "n"(64 / 4)
+            : "v50", "v51", "v52", "v53", "v54", "s90", "s91", "s92", "s93", "s94", "s95", "vcc", "scc");
+#undef ZK_STEP
+            c = ca - wbase;
+        }
+#else
+        {
+            const uint16_t *link = s_pd - (best - 2u);   /* link[c] is the link of the candidate */
+#pragma unroll 1
+            for (int it = 0; it < 64 / ZK_MATCH_STEPS; it++) {
+#pragma unroll
+                for (int u = 0; u < ZK_MATCH_STEPS; u++) {
+                    if (wm >= 0) continue;                            /* stopped lanes are masked off, their LDS reads with them */
+                    const uint32_t wi = c >> 2;
+                    const uint32_t v = __builtin_amdgcn_alignbyte(s_win[wi + 1], s_win[wi], c);
+                    const int32_t d = (int32_t)link[c];
+                    const uint32_t x = (v & 0x00ffffffu) ^ scan3;
+                    xlast = x;
+                    if (x == 0u || (plim - (int32_t)c) + d >= 0) wm = 0;      /* parked on this candidate, or the next one is out of reach */
+                    else c -= (uint32_t)d;
+                }
+                if (__popcll(__ballot(wm == 0)) >= ZK_MATCH_THRESH) break;
+            }
+        }
+#endif
+        cur = c - peek_off;
+        /* a walk that stopped in this round stands on the candidate that stopped it: it is parked if that
+         * candidate passed the peek */
+        parked = xlast == 0u ? (walking & ~wm) : 0;
+        /* a walk that ended without a parked candidate: its record is written here, outside the hot loop */
+        if ((walking & ~wm & ~parked) < 0) rec[pout] = make_uint2(full, qrec);
         walking = wm | parked;                /* parked walks are still owned by the lane */
     }
 }
@@ -1829,7 +2210,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         if (bi >= 1 && bi < (uint32_t)NS) HIPCHK(hipStreamWaitEvent(s, e->ev_init, 0));   /* memsets on stream 0 */
         if (P.parser == ZC_PARSE_SLOW) {
             tm_begin(e, s, 0, &slot);
-            hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(ZK_CHAIN_THREADS), 0, s, J);
+            hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(ZK_CHAIN_THREADS), 0, s, J, (int)ZK_CHAIN_REF);
             tm_end(e, s, slot);
         }
         /* k_match's records reproduce neither a nice length below the lazy limit nor a quarter budget of zero
@@ -1842,11 +2223,35 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
             tm_end(e, s, slot);
         }
         if (dense) {
-            tm_begin(e, s, 1, &slot);
-            {
-                const int rle = P.parser == ZC_PARSE_RLE ? 1 : 0;
-                hipLaunchKernelGGL(k_match, dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles, rle);
+            const int rle = P.parser == ZC_PARSE_RLE ? 1 : 0;
+            /* Chain budgets from 256 on (levels 7 to 9) search along the four-byte chains (k_match4): three more passes over
+             * the input set that up (how far the budget reaches, the nearest three-byte match, the chains themselves), which
+             * costs what about 60 candidate steps per position cost k_match, and saves what the hash chain's members of
+             * length 3 cost — most of a budget of 1 024 or 4 096, about as much as the set-up costs of one of 128 (measured:
+             * level 6 comes out the same either way, level 7 a sixth faster, levels 8 and 9 half as fast again and more).
+             * ZAMD_MATCH4_MIN_CHAIN moves the border (tests, measurements). */
+            static const uint32_t four_from = getenv("ZAMD_MATCH4_MIN_CHAIN") ? (uint32_t)strtoul(getenv("ZAMD_MATCH4_MIN_CHAIN"), nullptr, 10) : 256u;
+            const bool by_four = !rle && P.chain >= four_from && P.nice >= 4u;
+            if (by_four) {
+                /* per position: how far the chain budget reaches (from the hash chains), the nearest three-byte match (from
+                 * the exact three-byte chains, built in the hash chains' place), then the four-byte chains in theirs */
+                const uint32_t rtiles32 = (chunk_size + ZK_REACH_TILE - 1) / ZK_REACH_TILE;
+                tm_begin(e, s, 10, &slot);
+                hipLaunchKernelGGL(k_reach, dim3(J.nchunks * rtiles32), dim3(ZK_MATCH_THREADS), 0, s, J, rtiles32);
+                tm_end(e, s, slot);
+                tm_begin(e, s, 0, &slot);
+                hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(ZK_CHAIN_THREADS), 0, s, J, (int)ZK_CHAIN_THREE);
+                tm_end(e, s, slot);
+                tm_begin(e, s, 11, &slot);
+                hipLaunchKernelGGL(k_first3, dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles);
+                tm_end(e, s, slot);
+                tm_begin(e, s, 0, &slot);
+                hipLaunchKernelGGL(k_chain, dim3(J.nchunks), dim3(ZK_CHAIN_THREADS), 0, s, J, (int)ZK_CHAIN_FOUR);
+                tm_end(e, s, slot);
             }
+            tm_begin(e, s, 1, &slot);
+            if (by_four) hipLaunchKernelGGL(k_match4, dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles);
+            else hipLaunchKernelGGL(k_match, dim3(J.nchunks * tiles), dim3(ZK_MATCH_THREADS), 0, s, J, tiles, rle);
             tm_end(e, s, slot);
         }
         tm_begin(e, s, 2, &slot);
