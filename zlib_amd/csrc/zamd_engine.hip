@@ -393,9 +393,56 @@ __global__ __launch_bounds__(ZK_MATCH_THREADS) void k_first3(ZkJob J, uint32_t t
     LdsPd pd; pd.pd = s_pd; pd.a0 = (uint32_t)a0;
     /* the word waits where the symbols will be: those are written once k_match is through */
     uint32_t *const f3w = J.sym + (uint64_t)lc * J.P.chunk_size + tile * ZK_TILE;
-#pragma unroll 1
-    for (uint32_t i = tid; i < tlen; i += ZK_MATCH_THREADS)
-        f3w[i] = E - (t0 + i) >= ZC_MIN_MATCH ? zc_first3(win, pd, t0 + i, J.P.max_dist) : 0u;
+    /* zc_first3 for the thread's positions i = tid, tid + 1024, ...  The nearest member is the answer nearly
+     * everywhere, so every position takes its first step in straight-line code, sixteen positions' reads in flight
+     * together.  What is left — two strings that share a hash value — walks on one chain step per turn of a loop,
+     * whatever position a lane is at: a rare string that shares its value with a frequent one walks past hundreds of
+     * members, and a loop over positions would keep the whole wavefront waiting for it at every one of them. */
+    const uint32_t max_dist = J.P.max_dist, la0 = (uint32_t)a0;
+    uint32_t pend = 0;
+    {
+        uint32_t d[ZK_TILE / ZK_MATCH_THREADS], s3[ZK_TILE / ZK_MATCH_THREADS], c3[ZK_TILE / ZK_MATCH_THREADS];
+#pragma unroll
+        for (uint32_t j = 0; j < ZK_TILE / ZK_MATCH_THREADS; j++) {
+            const uint32_t i = j * ZK_MATCH_THREADS + tid, pp = t0 + (i < tlen ? i : 0u);
+            d[j] = s_pd[pp - la0];
+            s3[j] = win.load4(pp);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < ZK_TILE / ZK_MATCH_THREADS; j++) {
+            const uint32_t i = j * ZK_MATCH_THREADS + tid, pp = t0 + (i < tlen ? i : 0u);
+            const bool ok = d[j] <= max_dist && d[j] <= pp;                  /* "none" is 0xffff */
+            c3[j] = win.load4(ok ? pp - d[j] : pp);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < ZK_TILE / ZK_MATCH_THREADS; j++) {
+            const uint32_t i = j * ZK_MATCH_THREADS + tid, pp = t0 + i;
+            if (i >= tlen) continue;
+            const bool ok = d[j] <= max_dist && d[j] <= pp && E - pp >= ZC_MIN_MATCH;
+            if (!ok) f3w[i] = 0u;
+            else if (((c3[j] ^ s3[j]) & 0x00ffffffu) == 0u) f3w[i] = d[j];
+            else pend |= 1u << j;
+        }
+    }
+    uint32_t i = 0, p = 0, cur = 0, scan3 = 0;
+    bool fresh = true;
+    while (pend) {
+        if (fresh) {
+            i = ((uint32_t)__ffs((int)pend) - 1u) * ZK_MATCH_THREADS + tid; p = t0 + i;
+            cur = p - s_pd[p - la0];                     /* the member the first step found wanting */
+            scan3 = win.load4(p) & 0x00ffffffu;
+            fresh = false;
+        }
+        const uint32_t d = pd(cur);
+        uint32_t res = 0;
+        bool done = d == 0 || d > cur;
+        if (!done) {
+            cur -= d;
+            if (p - cur > max_dist) done = true;
+            else if ((win.load4(cur) & 0x00ffffffu) == scan3) { done = true; res = p - cur; }
+        }
+        if (done) { f3w[i] = res; pend &= pend - 1u; fresh = true; }
+    }
 }
 
 /* k_reach: the k-th predecessor in the hash chain by pointer jumping.  One workgroup per 32 Ki positions; the image of
