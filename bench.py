@@ -215,7 +215,8 @@ def main():
         lens = d_off[1:] - d_off[:-1]
         if args.backend == "gloo" and world > 1:
             lens = lens.cpu()
-        offs, gtotal = gather_offsets(lens, total_chunks, rank, world)   # RCCL all-gather + exclusive scan
+        # RCCL all-gather + exclusive scan (the library's zamd_chunk_offsets_dev); the total stays on the device
+        offs, gtotal = gather_offsets(lens, total_chunks, rank, world, engine=eng if lens.is_cuda else None, want_total=False)
         return total, gtotal
 
     def fence():
@@ -240,6 +241,7 @@ def main():
         total, gtotal = step()
     fence()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    gtotal = int(gtotal.item())
     ms_per_step = 1e3 * elapsed / max(1, args.steps)
     progress(rank, "timed steps done: %.1f ms per step" % ms_per_step)
     in_bytes_all = n * world
@@ -250,10 +252,12 @@ def main():
     # four streams, so an event pair around a launch measures a span that overlaps other kernels.  The roofline figure
     # therefore comes from one more, untimed, step with a single stream: every kernel alone on the GPU, event pairs
     # that add up to the step.
-    names = ["chain", "match", "parse", "plan", "layout", "emit", "call"]
-    kt = {nm: eng.timing_ms(i) for i, nm in enumerate(names)}
+    names = {"chain": 0, "match": 1, "parse": 2, "plan": 3, "layout": 4, "emit": 5, "call": 6, "reach": 10, "first3": 11}
+    kt = {nm: eng.timing_ms(i) for nm, i in names.items()}
     dominant = "match" if kt["match"][1] else "parse"     # levels 1-3 have no separate match kernel
-    kernel_name = "k_match" if dominant == "match" else ("k_fastw" if level == 1 else "k_fastr" if level in (2, 3) else "k_parse")
+    # chain budgets from 256 on (levels 7-9) search along the four-byte chains: k_reach and k_first3 ran, the matcher is k_match4
+    kernel_name = ("k_match4" if kt["reach"][1] else "k_match") if dominant == "match" else \
+                  ("k_fastw" if level == 1 else "k_fastr" if level in (2, 3) else "k_parse")
     roofline = None
     kt_serial = None
     if not args.no_serial_pass:
@@ -265,7 +269,7 @@ def main():
         serial_ms = 1e3 * (time.perf_counter() - t1)
         eng.set_streams(4, serialize=False)
         progress(rank, "serial pass done: %.1f ms" % serial_ms)
-        kt_serial = {nm: eng.timing_ms(i) for i, nm in enumerate(names)}
+        kt_serial = {nm: eng.timing_ms(i) for nm, i in names.items()}
         sum_ms, launches = kt_serial[dominant]
         if launches:
             avg_ms = sum_ms / launches
@@ -273,11 +277,11 @@ def main():
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             traffic, traffic_src = None, None
             try:                    # HBM bytes of this kernel from the PMC passes of this round, if they were committed
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
+                prof = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
                 ent = [v for k, v in prof["kernels"].items() if k.startswith(kernel_name)][0]
                 if prof.get("workload", "l6_mixed") == args.workload:
                     traffic = round(ent["hbm_bytes_per_input_byte"] * (n / launches) / 1e9, 3)
-                    traffic_src = "from_profile: profiles/r02_hbm_traffic.json (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction)"
+                    traffic_src = "from_profile: profiles/r03_hbm_traffic.json at commit %s (separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction)" % prof.get("commit", "?")
             except Exception:
                 pass
             roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(ach, 3), "peak": 8000.0, "unit": "GB/s",
@@ -345,7 +349,7 @@ def main():
         assert back == bytes(host[: 4 * CHUNK].numpy().tobytes()), "self-check failed: output does not inflate to the input"
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         exe = os.path.join(ROOT, "oracle", "_ref", "cpu_baseline")
         sample = args.cpu_sample_mib << 20
         cores = threads

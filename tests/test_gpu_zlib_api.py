@@ -203,6 +203,58 @@ def test_params_change_mid_stream():
     assert l.deflateEnd(C.byref(s)) == Z.Z_OK
 
 
+@pytest.mark.parametrize("first,then,cut,total,kind,exact", [
+    ((9, 0), (4, 3), 100000, 300000, 0, True), ((6, 0), (6, 1), 33333, 150000, 3, True), ((6, 0), (9, 4), 5, 90000, 2, True),
+    ((6, 2), (6, 0), 65536, 400000, 4, True), ((7, 1), (7, 0), 20000, 250000, 0, True),
+    ((5, 0), (8, 0), 131072, 500000, 0, False), ((2, 0), (1, 0), 60000, 180000, 0, False),
+    ((4, 0), (0, 0), 50000, 120000, 4, False), ((0, 0), (6, 0), 70000, 200000, 4, False),
+    ((6, 0), (1, 0), 40000, 100000, 0, False), ((1, 0), (6, 0), 70001, 200000, 4, False)])
+def test_params_change_mid_stream_is_the_reference_byte_for_byte(first, then, cut, total, kind, exact):
+    """deflateParams in the middle of a stream (deflate.c:490-528).  Where the change makes the reference end the block
+    (a new strategy, or a level that parses with another function: it then calls deflate(Z_BLOCK), :512-518) and both
+    sides parse with deflate_slow / deflate_rle / deflate_huff, the bytes are the reference's for inputs of at most one
+    chunk: what was taken so far is compressed with the old values and ends on a block boundary, the rest goes on behind
+    it, inside the same byte, with the new ones.
+    Not reproduced, and checked by round trip and check value only:
+    * a new level with the same function and strategy (5 -> 8, 2 -> 1): the reference ends no block there, and the last
+      lookahead of the first part (< MIN_LOOKAHEAD bytes it has not looked at yet, :1744-1747) is parsed with the new values;
+    * from or to deflate_fast / deflate_stored: the second part goes on with the hash chains the first part's function
+      left behind — every string (deflate_slow), some (deflate_fast, :1680-1697), none (deflate_stored) — and with its
+      prev_length, which longest_match takes as every later search's starting length (:1156) when deflate_fast, which
+      never sets it, takes over; deflate_stored cuts its blocks by where the stream stands in the window (:1571-1609).
+      A chunk primed with its history has every string entered and starts at window index w_size."""
+    ref = Z.ref_lib()
+    if ref is None:
+        pytest.skip("reference build not present")
+    P = C.POINTER(Z.ZStream)
+    ref.deflateInit2_.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    ref.deflate.argtypes = [P, C.c_int]; ref.deflateParams.argtypes = [P, C.c_int, C.c_int]; ref.deflateEnd.argtypes = [P]
+    data = O.corpus(total, kind, 210 + cut % 7)
+    src = C.create_string_buffer(data, len(data))
+
+    def run(l):
+        s = Z.ZStream()
+        obuf = C.create_string_buffer(2 * total + 4096)
+        assert l.deflateInit2_(C.byref(s), first[0], 8, 15, 8, first[1], Z.VERSION, Z.SZ) == 0
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), cut, C.addressof(obuf), 2 * total + 4096
+        assert l.deflate(C.byref(s), Z.Z_NO_FLUSH) == Z.Z_OK
+        assert l.deflateParams(C.byref(s), then[0], then[1]) == Z.Z_OK
+        assert s.avail_in == 0
+        s.avail_in = total - cut
+        assert l.deflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+        out = obuf.raw[:s.total_out]
+        adler = s.adler
+        assert l.deflateEnd(C.byref(s)) == Z.Z_OK
+        return out, adler
+
+    want, wadler = run(ref)
+    got, gadler = run(Z.lib())
+    assert zlib.decompress(got) == data
+    assert gadler == wadler
+    if exact:
+        assert got == want
+
+
 def test_tuned_stream_equals_the_tuned_reference():
     """deflateTune (deflate.c:531-547): values hold until deflateReset or a level change."""
     data = O.corpus(400000, 4, 77)

@@ -22,9 +22,13 @@ def shard_chunks(n_chunks: int, rank: int, world: int) -> Tuple[int, int]:
     return c0, c0 + base + (1 if rank < extra else 0)
 
 
-def gather_offsets(local_lens: torch.Tensor, n_chunks: int, rank: int, world: int) -> Tuple[torch.Tensor, int]:
+def gather_offsets(local_lens: torch.Tensor, n_chunks: int, rank: int, world: int, engine=None, want_total: bool = True):
     """All-gathers per-chunk compressed lengths (int64, on the tensor's device) and
-    returns (global byte offsets of this rank's chunks, global total)."""
+    returns (global byte offsets of this rank's chunks, global total).
+
+    With ``engine`` (a zlib_amd.Engine) and lengths on the GPU the exclusive scan is the library's own
+    (``zamd_chunk_offsets_dev``); ``want_total=False`` leaves the total on the device (a 0-d tensor), so
+    that a step of a timed loop ends without a copy to the host."""
     if world == 1:
         all_lens = local_lens
     else:
@@ -35,10 +39,18 @@ def gather_offsets(local_lens: torch.Tensor, n_chunks: int, rank: int, world: in
         out = torch.empty(world * width, dtype=torch.int64, device=local_lens.device)
         dist.all_gather_into_tensor(out, padded)
         all_lens = torch.cat([out[r * width: r * width + (c1 - c0)] for r, (c0, c1) in enumerate(counts)])
+    c0, c1 = shard_chunks(n_chunks, rank, world)
+    if engine is not None and all_lens.is_cuda and all_lens.numel():
+        all_lens = all_lens.contiguous()
+        offs = torch.empty(all_lens.numel() + 1, dtype=torch.int64, device=all_lens.device)
+        torch.cuda.current_stream().synchronize()     # the engine works on streams of its own: the lengths must have landed
+        engine.chunk_offsets(all_lens.data_ptr(), all_lens.numel(), offs.data_ptr())
+        total = offs[-1]
+        return offs[c0:c1], (int(total.item()) if want_total else total)
     csum = torch.cumsum(all_lens, 0)
     excl = csum - all_lens
-    c0, c1 = shard_chunks(n_chunks, rank, world)
-    return excl[c0:c1], int(csum[-1].item()) if csum.numel() else 0
+    total = csum[-1] if csum.numel() else torch.zeros((), dtype=torch.int64)
+    return excl[c0:c1], (int(total.item()) if want_total else total)
 
 
 def inflate_shard_handover(engine, rank: int, world: int, win_in: torch.Tensor, win_out: torch.Tensor, *begin_args, **begin_kw) -> None:
