@@ -107,6 +107,16 @@ int zamd_engine_pending_bits(zamd_engine *e, int *bits, int *value);
  * literal counts of the first block at level > 0): 0 Z_BINARY, 1 Z_TEXT, 2 Z_UNKNOWN (no block, or level 0). */
 int zamd_engine_data_type(zamd_engine *e);
 
+/* Split points for the next deflate call of this engine (only): besides the chunk offsets the call records, for every
+ * chunk, up to parts - 1 block boundaries that cut the chunk into parts of about equal output, so that a reader can put
+ * `parts` wavefronts on one chunk (zamd_inflate_split_dev).  d_splits (device) holds parts - 1 records per chunk, indexed
+ * by chunk number as d_chunk_off is: (bit offset of the block from the chunk's first byte) << 32 | offset of the block's
+ * first byte in the chunk's data, ascending, zeros behind the last one (a chunk of few blocks has fewer).  2 <= parts
+ * <= ZAMD_MAX_PARTS; d_splits = NULL cancels.  The reference has no counterpart: its access points are whole-window
+ * snapshots taken while inflating (examples/zran.c:249-349). */
+#define ZAMD_MAX_PARTS 16
+int zamd_engine_splits(zamd_engine *e, uint64_t *d_splits, uint32_t parts);
+
 /* deflatePrime (deflate.c:464-487) for the next deflate call of this engine only: `bits`
  * (0..7) low bits of `value` precede the first block of the call's first chunk, which
  * starts inside output byte 0 as it does in the reference after deflatePrime. */
@@ -162,6 +172,15 @@ int zamd_inflate_dev(zamd_engine *e, const void *d_comp, const uint64_t *d_chunk
  * i.e. the last 32 KiB produced by the previous shard. */
 int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
                            uint32_t chunk_size, const void *d_head_window, void *d_out, uint64_t n_out, int64_t *bad_chunk);
+
+/* The same with `parts` wavefronts to a chunk: d_splits (device, parts - 1 records per chunk) is what
+ * zamd_engine_splits made the deflate call record.  The records are hints of where blocks start: one that is out of
+ * order or outside its chunk ends its chunk's list, one that is not a block boundary makes its chunk fail
+ * (ZAMD_DATA_ERROR, *bad_chunk) like any other invalid data.  d_splits = NULL or parts < 2: zamd_inflate_shard_dev.
+ * chunk_size must be a multiple of 16. */
+int zamd_inflate_split_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                           uint32_t chunk_size, const uint64_t *d_splits, uint32_t parts, const void *d_head_window,
+                           void *d_out, uint64_t n_out, int64_t *bad_chunk);
 
 /*
  * The same in three steps, for ranks that hold consecutive shards of ONE stream and so do not have the window in

@@ -834,15 +834,34 @@ static int huff_decode(bitrd_t *b, const huff_t *h)
     return -1;
 }
 
+static int inflate_raw_from(const uint8_t *in, size_t in_len, uint64_t start_bit, const uint8_t *dict, size_t dict_len,
+                            uint8_t *out, size_t out_cap, size_t *consumed, size_t *produced,
+                            const char **msg, int stop_at_sync);
 int zo_inflate_raw(const uint8_t *in, size_t in_len, const uint8_t *dict, size_t dict_len,
                    uint8_t *out, size_t out_cap, size_t *consumed, size_t *produced,
                    const char **msg, int stop_at_sync)
 {
+    return inflate_raw_from(in, in_len, 0, dict, dict_len, out, out_cap, consumed, produced, msg, stop_at_sync);
+}
+/* The same from a block that starts at bit start_bit of the input (what inflatePrime with the first byte's upper bits
+ * sets up, inflate.c:232-253): stored blocks still align to the input's byte boundaries. */
+int zo_inflate_raw_at(const uint8_t *in, size_t in_len, uint64_t start_bit, const uint8_t *dict, size_t dict_len,
+                      uint8_t *out, size_t out_cap, size_t *consumed, size_t *produced,
+                      const char **msg, int stop_at_sync)
+{
+    return inflate_raw_from(in, in_len, start_bit, dict, dict_len, out, out_cap, consumed, produced, msg, stop_at_sync);
+}
+static int inflate_raw_from(const uint8_t *in, size_t in_len, uint64_t start_bit, const uint8_t *dict, size_t dict_len,
+                            uint8_t *out, size_t out_cap, size_t *consumed, size_t *produced,
+                            const char **msg, int stop_at_sync)
+{
     static const uint16_t lbase[29] = {3,4,5,6,7,8,9,10,11,13,15,17,19,23,27,31,35,43,51,59,67,83,99,115,131,163,195,227,258};
     static const uint16_t dbase[30] = {1,2,3,4,5,7,9,13,17,25,33,49,65,97,129,193,257,385,513,769,1025,1537,2049,3073,4097,6145,8193,12289,16385,24577};
     build_tables();
-    bitrd_t b = {in, in_len, 0, 0, 0, 0};
+    bitrd_t b = {in, in_len, (size_t)(start_bit >> 3), 0, 0, 0};
     size_t o = 0; int rc = 0, last = 0; const char *m = NULL;
+    if (start_bit >> 3 > in_len) { if (msg) *msg = NULL; return -5; }
+    if (start_bit & 7) { if (!need(&b, (int)(start_bit & 7))) { if (msg) *msg = NULL; return -5; } take(&b, (int)(start_bit & 7)); }
     huff_t *lh = (huff_t *)malloc(sizeof(huff_t)), *dh = (huff_t *)malloc(sizeof(huff_t)), *ch = (huff_t *)malloc(sizeof(huff_t));
     uint8_t lens[320];
 #define FAIL(t) do { m = (t); rc = -3; goto done; } while (0)

@@ -111,6 +111,10 @@ uint32_t zo_crc32_combine(uint32_t c1, uint32_t c2, int64_t len2);
 int zo_inflate_raw(const uint8_t *in, size_t in_len, const uint8_t *dict, size_t dict_len,
                    uint8_t *out, size_t out_cap, size_t *consumed, size_t *produced,
                    const char **msg, int stop_at_sync /* stop after an empty stored block */);
+/* the same from a block that starts at bit start_bit of `in` */
+int zo_inflate_raw_at(const uint8_t *in, size_t in_len, uint64_t start_bit, const uint8_t *dict, size_t dict_len,
+                      uint8_t *out, size_t out_cap, size_t *consumed, size_t *produced,
+                      const char **msg, int stop_at_sync);
 
 /* Deterministic corpus generator shared by fixtures and tests
  * (kinds: 0 text, 1 binary, 2 lowent, 3 image, 4 mixed). */

@@ -59,6 +59,9 @@ def lib():
         l.zo_inflate_raw.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_char_p), C.c_int]
         l.zo_inflate_raw.restype = C.c_int
+        l.zo_inflate_raw_at.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_char_p), C.c_int]
+        l.zo_inflate_raw_at.restype = C.c_int
         l.zo_corpus_fill.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint64]
         _lib = l
     return _lib
@@ -117,6 +120,15 @@ def adler32(data, value=1):
 
 def crc32(data, value=0):
     return lib().zo_crc32(value, bytes(data), len(data))
+
+
+def inflate_raw_at(comp, start_bit, dict_bytes=b"", out_cap=0, stop_at_sync=True):
+    """Serial decode from a block that starts at bit start_bit of comp, with dict_bytes as the window in front of it."""
+    out = C.create_string_buffer(out_cap + 1)
+    used, made, msg = C.c_size_t(0), C.c_size_t(0), C.c_char_p()
+    rc = lib().zo_inflate_raw_at(bytes(comp), len(comp), start_bit, bytes(dict_bytes), len(dict_bytes), out, out_cap,
+                                 C.byref(used), C.byref(made), C.byref(msg), int(stop_at_sync))
+    return rc, out.raw[:made.value], used.value, (msg.value.decode() if msg.value else None)
 
 
 def inflate_raw(comp, dict_bytes=b"", out_cap=0, stop_at_sync=False):

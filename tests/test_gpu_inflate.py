@@ -58,12 +58,73 @@ def test_round_trip_of_chunked_streams(engine, kind, n, level, strategy, chunk):
     assert out == data
 
 
+SPLIT_CASES = [(kind, (1 << 20) * 3 + 4321, 6, 0, 1 << 20, parts) for kind in range(5) for parts in (2, 5)]
+SPLIT_CASES += [(4, 700001, 9, 0, 65536, 3), (0, 700001, 1, 0, 131072, 16), (3, 500001, 6, 2, 1 << 18, 4), (3, 500001, 6, 3, 1 << 18, 4),
+                (1, 400000, 0, 0, 1 << 18, 4), (2, (1 << 20) + 5, 6, 0, 1 << 20, 8)]
+SPLIT_CASES += [(0, n, 6, 0, 32768, 4) for n in (0, 1, 5, 32768, 32769, 100000)]
+
+
+@pytest.mark.parametrize("kind,n,level,strategy,chunk,parts", SPLIT_CASES)
+def test_round_trip_with_several_wavefronts_to_a_chunk(engine, kind, n, level, strategy, chunk, parts):
+    # the deflate call records block boundaries inside every chunk; the inflate call starts a wavefront at each
+    data = O.corpus(n, kind, 31 + kind)
+    stream, offs, splits = engine.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk, parts=parts)
+    plain, offs2 = engine.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk)
+    assert stream == plain and offs == offs2                      # recording changes nothing in the stream
+    nch = len(offs) - 1
+    assert len(splits) == nch * (parts - 1)
+    for c in range(nch):
+        recs = [r for r in splits[c * (parts - 1):(c + 1) * (parts - 1)]]
+        live = [r for r in recs if r]
+        assert recs == live + [0] * (len(recs) - len(live))          # packed to the front
+        assert live == sorted(live) and len(set(live)) == len(live)
+        clen = min(chunk, n - c * chunk)
+        for r in live:
+            bit, off = r >> 32, r & 0xffffffff
+            assert 0 < off < clen and 0 < bit < 8 * (offs[c + 1] - offs[c])
+            # a serial decoder that starts at the recorded bit with the data in front of it as window produces the rest
+            rc, want, used, msg = O.inflate_raw_at(stream[offs[c]:offs[c + 1]], bit, data[max(0, c * chunk + off - 32768):c * chunk + off], clen - off)
+            assert want == data[c * chunk + off:c * chunk + clen], (c, r, msg)
+    if n >= 3 * chunk and chunk >= (1 << 20) and level >= 4 and kind != 1:
+        assert any(splits), "chunks of several blocks must come with split points"
+    assert engine.inflate_chunks(stream, offs, n, chunk_size=chunk, splits=splits, parts=parts) == data
+    if n > chunk + 40000:
+        # a shard of the stream with the window in front of it
+        k = 1
+        out = engine.inflate_chunks(stream[offs[k]:], [o - offs[k] for o in offs[k:]], n - k * chunk, chunk_size=chunk,
+                                    head_window=data[k * chunk - 32768:k * chunk], splits=splits[k * (parts - 1):], parts=parts)
+        assert out == data[k * chunk:]
+
+
+def test_split_records_are_hints(engine):
+    # records that are out of order or outside the chunk end the chunk's list; a record that is not a block boundary
+    # makes the chunk fail like other bad data; nothing reads or writes outside its buffers
+    data = O.corpus(4 * 262144 + 999, 0, 6)
+    chunk, parts = 262144, 4
+    stream, offs, splits = engine.deflate_chunks(data, level=6, chunk_size=chunk, parts=parts)
+    assert all(splits[c * 3] for c in range(4))
+    junk = list(splits)
+    junk[0], junk[1] = splits[1], splits[0]                          # out of order: the second ends the list
+    junk[3] = (0xfffffff0 << 32) | 5                                   # a bit offset far outside chunk 1
+    junk[6] = (splits[6] & ~0xffffffff) | (chunk + 7)                # an output offset outside chunk 2
+    assert engine.inflate_chunks(stream, offs, len(data), chunk_size=chunk, splits=junk, parts=parts) == data
+    wrong = list(splits)
+    wrong[4] += 3 << 32                                              # three bits behind a block boundary of chunk 1
+    with pytest.raises(zlib_amd.ZamdError) as ei:
+        engine.inflate_chunks(stream, offs, len(data), chunk_size=chunk, splits=wrong, parts=parts)
+    assert ei.value.code == zlib_amd.Z_DATA_ERROR and ei.value.segment == 1
+
+
 def test_long_range_window_propagation(engine):
     # every chunk starts by copying from the previous one, and runs of one byte cross many chunks
     data = b"\0" * 200000 + O.corpus(100000, 0, 3) + b"\xff" * 150000 + O.corpus(70000, 0, 3) * 3
     for chunk in (32768, 65536):
         stream, offs = engine.deflate_chunks(data, level=9, chunk_size=chunk)
         assert engine.inflate_chunks(stream, offs, len(data), chunk_size=chunk) == data
+    # parts shorter than the window: a byte may come from the part before the part before
+    stream, offs, splits = engine.deflate_chunks(data, level=1, mem_level=1, chunk_size=131072, parts=16)
+    assert sum(1 for r in splits if r) > 40
+    assert engine.inflate_chunks(stream, offs, len(data), chunk_size=131072, splits=splits, parts=16) == data
 
 
 @pytest.mark.parametrize("level,wbits_data", [(1, 0), (6, 1), (9, 4)])

@@ -91,6 +91,10 @@ def load_library() -> C.CDLL:
     lib.zamd_inflate_dev.restype = i32
     lib.zamd_inflate_shard_dev.argtypes = [vp, vp, u64, vp, u64, u32, vp, vp, u64, C.POINTER(C.c_int64)]
     lib.zamd_inflate_shard_dev.restype = i32
+    lib.zamd_inflate_split_dev.argtypes = [vp, vp, u64, vp, u64, u32, vp, u32, vp, vp, u64, C.POINTER(C.c_int64)]
+    lib.zamd_inflate_split_dev.restype = i32
+    lib.zamd_engine_splits.argtypes = [vp, vp, u32]
+    lib.zamd_engine_splits.restype = i32
     lib.zamd_inflate_shard_begin_dev.argtypes = [vp, vp, u64, vp, u64, u32, i32, vp, u64, C.POINTER(C.c_int64)]
     lib.zamd_inflate_shard_begin_dev.restype = i32
     lib.zamd_inflate_shard_tail_dev.argtypes = [vp, vp, vp]
@@ -276,11 +280,15 @@ class Engine:
 
     # -- host convenience (upload, run on the GPU, download) ---------------------------
     def deflate_chunks(self, data, *, level: int = 6, strategy: int = 0, mem_level: int = 8,
-                       chunk_size: int = 1 << 20, finish: bool = True, dictionary: bytes = b"") -> Tuple[bytes, List[int]]:
+                       chunk_size: int = 1 << 20, finish: bool = True, dictionary: bytes = b"", parts: int = 0):
         """Chunked raw deflate of host bytes; returns (stream, chunk offsets + total).  `dictionary` (at most the
-        window size) primes the first chunk as deflateSetDictionary does."""
+        window size) primes the first chunk as deflateSetDictionary does.  parts >= 2: a third value, the
+        parts - 1 split records of every chunk (see record_splits)."""
         n = len(data)
         nchunks = max(1, (n + chunk_size - 1) // chunk_size)
+        d_sp = self.alloc(8 * nchunks * (parts - 1)) if parts >= 2 else None
+        if d_sp is not None:
+            self.record_splits(d_sp.ptr, parts)
         cap = self.lib.zamd_deflate_bound(n, chunk_size, mem_level)
         d_stage = self.alloc(32768 + max(n, 16))
         d_in = DeviceBuffer.__new__(DeviceBuffer)
@@ -299,9 +307,13 @@ class Engine:
                                          chunk_size=chunk_size, finish=finish, d_chunk_off=d_off.ptr)
             out = bytes(d_out.download(total))
             offs = list(memoryview(d_off.download(8 * (nchunks + 1))).cast("Q"))
+            splits = list(memoryview(d_sp.download(8 * nchunks * (parts - 1))).cast("Q")) if d_sp is not None else None
         finally:
+            self.record_splits(0, 0)
             d_in.free(); d_out.free(); d_off.free()
-        return out, offs
+            if d_sp is not None:
+                d_sp.free()
+        return (out, offs, splits) if splits is not None else (out, offs)
 
     def adler32(self, data, value: int = 1) -> int:
         n = len(data)
@@ -331,11 +343,20 @@ class Engine:
         self.lib.zamd_inflate_last_error(self.handle, C.byref(seg), C.byref(st))
         return ZamdError(rc, what, self.lib.zamd_inflate_message(st.value).decode(), seg.value)
 
+    def record_splits(self, d_splits: int, parts: int) -> None:
+        """The next deflate call also records parts - 1 split points per chunk into d_splits (uint64 each)."""
+        _chk(self.lib.zamd_engine_splits(self.handle, d_splits or None, parts), "zamd_engine_splits")
+
     def inflate_dev(self, d_comp: int, d_chunk_off: int, n_chunks: int, d_out: int, n_out: int, *,
-                    chunk_size: int = 1 << 20, comp_bytes: Optional[int] = None, d_head_window: int = 0) -> None:
-        """Batch inflate of a chunk-indexed raw deflate stream (device pointers)."""
+                    chunk_size: int = 1 << 20, comp_bytes: Optional[int] = None, d_head_window: int = 0,
+                    d_splits: int = 0, parts: int = 0) -> None:
+        """Batch inflate of a chunk-indexed raw deflate stream (device pointers); with d_splits (as record_splits made
+        the deflate call write them) `parts` wavefronts share a chunk."""
         bad = C.c_int64(-1)
-        if comp_bytes is None:
+        if d_splits:
+            rc = self.lib.zamd_inflate_split_dev(self.handle, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size,
+                                                 d_splits, parts, d_head_window or None, d_out, n_out, C.byref(bad))
+        elif comp_bytes is None:
             rc = self.lib.zamd_inflate_dev(self.handle, d_comp, d_chunk_off, n_chunks, chunk_size, d_out, n_out, C.byref(bad))
         else:
             rc = self.lib.zamd_inflate_shard_dev(self.handle, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size,
@@ -369,10 +390,13 @@ class Engine:
     def inflate_shard_finish(self, d_head_window: int) -> None:
         _chk(self.lib.zamd_inflate_shard_finish_dev(self.handle, d_head_window or None), "zamd_inflate_shard_finish_dev")
 
-    def inflate_chunks(self, stream, offsets, n_out: int, *, chunk_size: int = 1 << 20, head_window=None) -> bytes:
-        """Host convenience around inflate_dev: offsets = chunk offsets + total, as deflate_chunks returns."""
+    def inflate_chunks(self, stream, offsets, n_out: int, *, chunk_size: int = 1 << 20, head_window=None,
+                       splits=None, parts: int = 0) -> bytes:
+        """Host convenience around inflate_dev: offsets = chunk offsets + total, as deflate_chunks returns; splits and
+        parts as deflate_chunks(parts=...) returned them."""
         import struct
         n_chunks = len(offsets) - 1
+        d_sp = self.alloc(8 * max(1, len(splits))) if splits is not None else None
         d_comp = self.alloc(len(stream) + 16)
         d_off = self.alloc(8 * len(offsets))
         d_out = self.alloc(max(n_out, 16))
@@ -382,11 +406,16 @@ class Engine:
             d_off.upload(struct.pack(f"<{len(offsets)}Q", *offsets))
             if d_head is not None:
                 d_head.upload(head_window)
+            if d_sp is not None:
+                d_sp.upload(struct.pack(f"<{len(splits)}Q", *splits))
             self.inflate_dev(d_comp.ptr, d_off.ptr, n_chunks, d_out.ptr, n_out, chunk_size=chunk_size,
-                             comp_bytes=len(stream), d_head_window=d_head.ptr if d_head else 0)
+                             comp_bytes=len(stream), d_head_window=d_head.ptr if d_head else 0,
+                             d_splits=d_sp.ptr if d_sp is not None else 0, parts=parts)
             return bytes(d_out.download(n_out))
         finally:
             d_comp.free(); d_off.free(); d_out.free()
+            if d_sp is not None:
+                d_sp.free()
             if d_head is not None:
                 d_head.free()
 

@@ -68,6 +68,7 @@ struct ZkJob {
     uint32_t *out32; uint64_t out_cap;
     uint32_t *err;
     uint16_t *fhead;              /* levels 1-3: head table of every chunk of the batch, 65536 entries each */
+    uint64_t *splits; uint32_t split_parts;   /* split records of every chunk (global table, split_parts - 1 per chunk), or null */
 };
 
 /* ------------------------------------------------------------------ k_chain
@@ -1609,6 +1610,22 @@ __global__ void k_layout(ZkJob J)
                                         call_end ? J.P.tail : (uint32_t)ZC_TAIL_SYNC, &left);
     J.sync_bit[lc] = sync;
     if (call_end) J.err[3] = left;
+    if (J.splits) {
+        /* where a reader may cut the chunk into split_parts parts of about the same output: for part k the first block
+         * that starts at or behind k / split_parts of the chunk's data, as (bit offset from the chunk's first byte) << 32 |
+         * offset of the block's first byte in the chunk's data; strictly ascending, packed to the front, zeros behind */
+        uint64_t *sp = J.splits + (J.chunk0 + lc) * (uint64_t)(J.split_parts - 1u);
+        const uint32_t nb = J.nblk[lc];
+        uint32_t j = 1, last_off = 0, w = 0;
+        for (uint32_t k = 1; k < J.split_parts; k++) {
+            const uint32_t target = g.dict_len + (uint32_t)((uint64_t)g.len * k / J.split_parts);
+            while (j < nb && base[j].in_start < target) j++;
+            if (j >= nb) break;
+            const uint32_t off = base[j].in_start - g.dict_len;
+            if (off > last_off && off < g.len) { sp[w++] = (base[j].bit_off << 32) | off; last_off = off; }
+        }
+        while (w < J.split_parts - 1u) sp[w++] = 0;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_scan(ZkJob J)
@@ -1937,6 +1954,7 @@ struct zamd_engine {
     uint32_t prime_bits, prime_val;   /* deflatePrime residue for the next deflate call only */
     int wbits;                        /* windowBits of the following deflate calls (9..15) */
     uint32_t tail_mode;               /* ZC_TAIL_* for the next deflate call only */
+    uint64_t *split_out; uint32_t split_parts;   /* where the next deflate call (only) records its chunks' split points */
     uint32_t pend_bits, pend_val;     /* bits the last call left behind its last complete byte */
     int data_type;                    /* detect_data_type of the last call's first block, or Z_UNKNOWN (2) */
     int tuned; uint32_t tune[4];   /* deflateTune values for the following calls (good, lazy, nice, chain) */
@@ -2103,6 +2121,13 @@ extern "C" int zamd_engine_tail(zamd_engine *e, int mode)
     return ZAMD_OK;
 }
 
+extern "C" int zamd_engine_splits(zamd_engine *e, uint64_t *d_splits, uint32_t parts)
+{
+    if (!e || (d_splits && (parts < 2 || parts > ZAMD_MAX_PARTS))) return ZAMD_STREAM_ERROR;
+    e->split_out = d_splits; e->split_parts = d_splits ? parts : 0u;
+    return ZAMD_OK;
+}
+
 extern "C" int zamd_engine_pending_bits(zamd_engine *e, int *bits, int *value)
 {
     if (!e) return ZAMD_STREAM_ERROR;
@@ -2197,6 +2222,8 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
     P.tail = e->tail_mode; e->tail_mode = ZC_TAIL_SYNC;
     const uint32_t prime_bits = e->prime_bits, prime_val = e->prime_val;
     e->prime_bits = 0; e->prime_val = 0;
+    uint64_t *const split_out = e->split_out; const uint32_t split_parts = e->split_parts;
+    e->split_out = nullptr; e->split_parts = 0;
     e->pend_bits = 0; e->pend_val = 0; e->data_type = 2;
     const auto host_t0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(e->device));
@@ -2253,6 +2280,7 @@ extern "C" int zamd_deflate_shard_dev(zamd_engine *e, const void *d_in, uint64_t
         J.chunk_bytes = w.chunk_bytes; J.sync_bit = w.sync_bit;
         J.chunk_off = d_off; J.running_total = e->d_total;
         J.out32 = (uint32_t *)d_out; J.out_cap = out_cap; J.err = e->d_err;
+        J.splits = split_out; J.split_parts = split_parts;
         int slot;
         if (bi >= 1 && bi < (uint32_t)NS) HIPCHK(hipStreamWaitEvent(s, e->ev_init, 0));   /* memsets on stream 0 */
         if (P.parser == ZC_PARSE_SLOW) {

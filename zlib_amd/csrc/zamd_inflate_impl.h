@@ -684,14 +684,27 @@ __global__ __launch_bounds__(1024) void k_inf_ref_init(const ZiSeg *segs, const 
     const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
     const ZiSeg S = segs[si];
     const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
-    if (e >= tl) { ref[(uint64_t)si * 32768u + e] = 0x80000000u; return; }   /* every slot is read by the jump rounds */
-    const uint32_t v = out16[S.out_off + S.out_len - tl + e];
-    uint32_t r;
-    if (v < ZI_MARK) r = 0x80000000u | v;
-    else if (si == 0) r = head ? (ZI_REF_BYTE | head[v - ZI_MARK]) : (ZI_REF_HEAD | (v - ZI_MARK));
-    else r = (si - 1u) * 32768u + (v - ZI_MARK);
+    uint32_t r = 0x80000000u;                            /* slots behind a short tail: every slot is read by the jump rounds */
+    if (e < tl) {
+        const uint32_t v = out16[S.out_off + S.out_len - tl + e];
+        if (v < ZI_MARK) r = 0x80000000u | v;
+        else {
+            /* the byte lies less than 32 KiB in front of this segment, so inside the last 32 KiB of whichever segment holds it
+             * (segments are back to back; short and empty ones are stepped over) or in the window in front of them all */
+            const int64_t q = (int64_t)S.out_off - 32768 + (int64_t)(v - ZI_MARK);
+            int64_t sj = (int64_t)si - 1;
+            while (sj >= 0 && (int64_t)segs[sj].out_off > q) sj--;
+            if (sj < 0) r = head ? (ZI_REF_BYTE | head[32768 + q]) : (ZI_REF_HEAD | (uint32_t)(32768 + q));
+            else {
+                const uint64_t lj = segs[sj].out_len, tj = lj < 32768 ? lj : 32768;
+                r = (uint32_t)sj * 32768u + (uint32_t)((uint64_t)q - (segs[sj].out_off + lj - tj));
+            }
+        }
+    }
     ref[(uint64_t)si * 32768u + e] = r;
 }
+/* One jump round.  (Chains are as long as the data's history: in repetitive data nearly every group of 64 slots holds
+ * a reference until the last rounds, so there is nothing to gain from skipping groups that hold none — measured.) */
 __global__ __launch_bounds__(256) void k_inf_ref_jump(uint32_t *ref, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -730,14 +743,18 @@ __global__ __launch_bounds__(1024) void k_inf_tail_window(const ZiSeg *segs, uin
 }
 
 /* Everything in front of the tails: 8 elements per thread. */
-__global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t nseg, uint32_t chunk_size, const uint16_t *out16,
+/* chunk_size != 0: segment tables of `parts` entries per chunk, the parts of a chunk in stream order with the unused
+ * entries (empty, placed at the chunk's end) behind them */
+__global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t nseg, uint32_t chunk_size, uint32_t parts, const uint16_t *out16,
                                                    uint8_t *out8, const uint8_t *head, uint64_t total)
 {
     const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
     if (p0 >= total) return;
     uint64_t si;
-    if (chunk_size) si = p0 / chunk_size;
-    else {
+    if (chunk_size) {
+        si = p0 / chunk_size * parts;
+        for (uint32_t k = 1; k < parts && segs[si + 1].out_off <= p0; k++) si++;
+    } else {
         uint64_t lo = 0, hi = nseg - 1;
         while (lo < hi) { uint64_t mid = (lo + hi + 1) >> 1; if (segs[mid].out_off <= p0) lo = mid; else hi = mid - 1; }
         si = lo;
@@ -824,7 +841,7 @@ static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems, bool r
 /* decode (+ resolve when d_out != NULL) the segments already in z->d_segs */
 static int zi_finish(zamd_engine *e, const void *d_head);
 static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint64_t nseg, uint32_t chunk_size,
-                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg, bool regular_tails, bool defer = false)
+                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg, bool regular_tails, bool defer = false, uint32_t parts = 1)
 {
     ZiState *z = e->inf;
     hipStream_t s = e->st[0];
@@ -850,7 +867,7 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
     }
     if (d_out && rc == ZAMD_OK && out_bytes) {
         tm_begin(e, s, 8, &slot);
-        if (regular_tails && nseg < 32768 && (defer || !getenv("ZAMD_INF_SERIAL_TAILS"))) {
+        if (regular_tails && nseg <= 32768 && (defer || !getenv("ZAMD_INF_SERIAL_TAILS"))) {
             const uint64_t nref = nseg * 32768ull;
             hipLaunchKernelGGL(k_inf_ref_init, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, defer ? (const uint8_t *)nullptr : (const uint8_t *)d_head, z->d_mlist);
             uint32_t rounds = 1;
@@ -872,7 +889,7 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
             hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, (uint8_t *)d_out, z->d_marks, z->d_mlist, (const uint8_t *)d_head);
         }
         uint64_t groups = (out_bytes + 2047) / 2048;
-        hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, chunk_size, z->d_stage, (uint8_t *)d_out, (const uint8_t *)d_head, out_bytes);
+        hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, chunk_size, parts, z->d_stage, (uint8_t *)d_out, (const uint8_t *)d_head, out_bytes);
         tm_end(e, s, slot);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s));
@@ -898,6 +915,77 @@ extern "C" int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64
     return zi_run(e, d_comp, comp_bytes, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk, chunk_size >= 32768);
 }
 
+/* Segment table of a chunk-indexed stream whose chunks come with split points (block boundaries inside the chunk, as
+ * the deflate side records them): `parts` entries per chunk, the parts of the chunk in stream order, unused entries
+ * empty at the chunk's end.  A split record is (bit offset from the chunk's first byte) << 32 | offset of the
+ * block's first byte in the chunk's output; records must ascend in both halves and stay inside the chunk, and the
+ * first one that does not ends the chunk's list (the rest of the chunk is then one part). */
+__global__ void k_inf_setup_parts(const uint64_t *chunk_off, uint64_t nchunks, uint32_t chunk_size, uint64_t n_out, uint64_t out_base,
+                                  uint32_t head_avail, const uint64_t *splits, uint32_t parts, ZiSeg *segs)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nchunks) return;
+    const uint64_t bit0 = chunk_off[i] * 8ull, bit1 = chunk_off[i + 1] * 8ull, o0 = i * (uint64_t)chunk_size;
+    const uint64_t rest = n_out > o0 ? n_out - o0 : 0, clen = rest < chunk_size ? rest : chunk_size;
+    ZiSeg *out = segs + i * parts;
+    uint32_t idx = 0;
+    uint64_t pbit = bit0, pout = 0;
+    auto put = [&](uint64_t b0, uint64_t b1, uint64_t off, uint64_t cap) {
+        ZiSeg s;
+        s.in_bit = b0; s.in_end_bit = b1; s.out_off = o0 + off; s.out_cap = cap;
+        const uint64_t before = out_base + s.out_off + head_avail;
+        s.win_avail = (uint32_t)(before < 32768 ? before : 32768);
+        s.mode = ZI_MODE_EXACT;
+        s.out_len = 0; s.end_bit = 0; s.status = 0xffffffffu; s.final_seen = 0; s.stop_bit = 0;
+        out[idx++] = s;
+    };
+    for (uint32_t k = 0; k + 1 < parts; k++) {
+        const uint64_t rec = splits[i * (parts - 1u) + k];
+        const uint64_t bit = bit0 + (rec >> 32), off = rec & 0xffffffffull;
+        if (rec == 0 || off <= pout || off >= clen || bit <= pbit || bit >= bit1) break;
+        put(pbit, bit, pout, off - pout);
+        pbit = bit; pout = off;
+    }
+    put(pbit, bit1, pout, clen - pout);
+    while (idx < parts) put(bit1, bit1, clen, 0);
+}
+
+extern "C" int zamd_inflate_split_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
+                                      uint32_t chunk_size, const uint64_t *d_splits, uint32_t parts, const void *d_head_window,
+                                      void *d_out, uint64_t n_out, int64_t *bad_chunk)
+{
+    if (!d_splits || parts < 2)
+        return zamd_inflate_shard_dev(e, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk);
+    if (!e || !d_comp || !d_chunk_off || !d_out || chunk_size == 0 || (chunk_size & 15u) || parts > ZAMD_MAX_PARTS) return ZAMD_STREAM_ERROR;
+    if (((uintptr_t)d_comp & 3u) || ((uintptr_t)d_out & 15u)) return ZAMD_STREAM_ERROR;
+    if (n_chunks == 0 || n_chunks > 0x7fffffffull / 32 / parts) return ZAMD_STREAM_ERROR;
+    if ((n_out + chunk_size - 1) / chunk_size > n_chunks) return ZAMD_STREAM_ERROR;
+    HIPCHK(hipSetDevice(e->device));
+    /* the references of the resolve step are 30 bits wide: 32 768 segments to a round, each round on top of the output
+     * of the one before it */
+    const uint64_t per_round = 32768u / parts;
+    const uint64_t first = n_chunks < per_round ? n_chunks : per_round;
+    int rc = zi_ensure(e, first * parts, first * (uint64_t)chunk_size, true);
+    if (rc) return rc;
+    double t_dec = 0, t_res = 0; int n_dec = 0, n_res = 0;
+    for (uint64_t c0 = 0; c0 < n_chunks; c0 += per_round) {
+        const uint64_t nc = n_chunks - c0 < per_round ? n_chunks - c0 : per_round;
+        const uint64_t o0 = c0 * (uint64_t)chunk_size;
+        const uint64_t out_here = n_out > o0 ? n_out - o0 : 0;
+        const uint8_t *head = c0 ? (const uint8_t *)d_out + o0 - 32768 : (const uint8_t *)d_head_window;
+        hipLaunchKernelGGL(k_inf_setup_parts, dim3((uint32_t)((nc + 255) / 256)), dim3(256), 0, e->st[0], d_chunk_off + c0, nc, chunk_size, out_here, o0,
+                           d_head_window ? 32768u : 0u, d_splits + c0 * (parts - 1u), parts, e->inf->d_segs);
+        int64_t bad = -1;
+        rc = zi_run(e, d_comp, comp_bytes, nc * parts, chunk_size, head, (uint8_t *)d_out + o0, out_here < nc * (uint64_t)chunk_size ? out_here : nc * (uint64_t)chunk_size,
+                    &bad, true, false, parts);
+        if (rc == ZAMD_DATA_ERROR) { e->inf->last_seg = (int64_t)c0 + bad / (int64_t)parts; if (bad_chunk) *bad_chunk = e->inf->last_seg; }
+        if (rc) return rc;
+        t_dec += e->t_ms[7]; n_dec += e->t_n[7]; t_res += e->t_ms[8]; n_res += e->t_n[8];
+    }
+    e->t_ms[7] = t_dec; e->t_n[7] = n_dec; e->t_ms[8] = t_res; e->t_n[8] = n_res;
+    return ZAMD_OK;
+}
+
 /* Second half of a deferred zi_run: the window in front of the shard has arrived. */
 static int zi_finish(zamd_engine *e, const void *d_head)
 {
@@ -908,7 +996,7 @@ static int zi_finish(zamd_engine *e, const void *d_head)
     tm_begin(e, s, 8, &slot);
     hipLaunchKernelGGL(k_inf_ref_write, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, (uint8_t *)z->pend_out, (const uint8_t *)d_head);
     const uint64_t groups = (z->pend_out_bytes + 2047) / 2048;
-    hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, z->pend_chunk, z->d_stage, (uint8_t *)z->pend_out, (const uint8_t *)d_head, z->pend_out_bytes);
+    hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, z->pend_chunk, 1u, z->d_stage, (uint8_t *)z->pend_out, (const uint8_t *)d_head, z->pend_out_bytes);
     tm_end(e, s, slot);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
