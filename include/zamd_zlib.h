@@ -213,6 +213,14 @@ int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_ch
                                                              /* after inflateInit/Reset: the index of the deflate data that
                                                                 follows; inflate() then places whole chunks in one pass.  A
                                                                 hint that does not fit the data is dropped, not trusted */
+/* Block boundaries inside the chunks, recorded with the index: per_chunk records for every chunk of the index, each
+ * (bit offset of a block from the chunk's first byte) << 32 | offset of the block's first byte in the chunk's data,
+ * ascending, zeros behind the last one.  With them inflate() puts several wavefronts on a chunk, and a round of chunks
+ * is decoded, checked and copied to the caller's buffer in overlapped groups.  Hints like the index itself. */
+int zamd_deflate_index_splits(z_streamp strm, const unsigned long long **recs, unsigned *per_chunk);
+                                                             /* with zamd_deflate_index_get */
+int zamd_inflate_index_hint_splits(z_streamp strm, const unsigned long long *recs, unsigned per_chunk);
+                                                             /* directly after zamd_inflate_index_hint */
 /* adler32() and crc32() (zlib.h:1569-1617) have no way to report a failure, and this library can fail where the
  * reference cannot (no GPU, no device memory): such a call writes a line to stderr, hands its running value back
  * unchanged and leaves its error code here.  Returns 0 or that code, and clears it.  No counterpart in the reference. */

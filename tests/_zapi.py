@@ -110,6 +110,8 @@ def lib():
         l.zamd_deflate_index.argtypes = [P, C.c_int]
         l.zamd_deflate_index_get.argtypes = [P, C.POINTER(C.POINTER(C.c_uint)), C.POINTER(C.c_uint)]
         l.zamd_inflate_index_hint.argtypes = [P, C.POINTER(C.c_uint), C.c_uint]
+        l.zamd_deflate_index_splits.argtypes = [P, C.POINTER(C.POINTER(C.c_ulonglong)), C.POINTER(C.c_uint)]
+        l.zamd_inflate_index_hint_splits.argtypes = [P, C.POINTER(C.c_ulonglong), C.c_uint]
         l.zamd_gz_index_load.argtypes = [C.c_int, C.POINTER(GzIndex)]
         l.zamd_gz_index_free.argtypes = [C.POINTER(GzIndex)]; l.zamd_gz_index_free.restype = None
         _lib = l
@@ -137,7 +139,7 @@ def uncompress(comp, cap):
     return rc, buf.raw[:n.value] if rc == 0 else b""
 
 
-def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out_step=65536, flushes=None, header=None, index=None):
+def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out_step=65536, flushes=None, header=None, index=None, splits=None):
     """Feeds `data` through deflate() in in_step slices with out_step output space per call.
     flushes: {offset: flush} applied when the input cursor reaches offset.  Returns (rc_list_tail, bytes, strm)."""
     l = lib()
@@ -194,11 +196,16 @@ def deflate_stream(data, level=6, wbits=15, mem=8, strategy=0, in_step=None, out
         rc = l.zamd_deflate_index_get(C.byref(s), C.byref(pairs), C.byref(cnt))
         index.append(rc)
         index.extend((pairs[2 * i], pairs[2 * i + 1]) for i in range(cnt.value))
+        if splits is not None and rc == 0:     # a list that receives the records per chunk, then all the split records
+            recs, per = C.POINTER(C.c_ulonglong)(), C.c_uint(0)
+            assert l.zamd_deflate_index_splits(C.byref(s), C.byref(recs), C.byref(per)) == 0
+            splits.append(per.value)
+            splits.extend(recs[:per.value * cnt.value])
     assert l.deflateEnd(C.byref(s)) == 0
     return bytes(out), totals
 
 
-def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUSH, header=None, dictionary=None, hint=None):
+def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUSH, header=None, dictionary=None, hint=None, hint_splits=None):
     """Feeds `comp` through inflate().  Returns (rc, bytes, msg, unused_input, totals)."""
     l = lib()
     s = ZStream()
@@ -209,6 +216,9 @@ def inflate_stream(comp, wbits=15, in_step=None, out_step=65536, flush=Z_NO_FLUS
     if hint is not None:                       # [(compressed bytes, inflated bytes), ...] of the deflate data
         flat = (C.c_uint * (2 * len(hint)))(*[v for pair in hint for v in pair])
         assert l.zamd_inflate_index_hint(C.byref(s), flat, len(hint)) == 0
+        if hint_splits:                        # [records per chunk, record, record, ...] as deflate_stream(splits=) filled it
+            recs = (C.c_ulonglong * (len(hint_splits) - 1))(*hint_splits[1:])
+            assert l.zamd_inflate_index_hint_splits(C.byref(s), recs, hint_splits[0]) == 0
     src = C.create_string_buffer(bytes(comp), max(len(comp), 1))
     obuf = C.create_string_buffer(out_step)
     out = bytearray()

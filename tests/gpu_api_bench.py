@@ -40,18 +40,23 @@ for it in range(2):
     pairs, cnt = C.POINTER(C.c_uint)(), C.c_uint(0)
     assert l.zamd_deflate_index_get(C.byref(s), C.byref(pairs), C.byref(cnt)) == 0
     index = (C.c_uint * (2 * cnt.value))(*pairs[:2 * cnt.value])
+    recs, per = C.POINTER(C.c_ulonglong)(), C.c_uint(0)
+    assert l.zamd_deflate_index_splits(C.byref(s), C.byref(recs), C.byref(per)) == 0
+    splits = (C.c_ulonglong * (per.value * cnt.value))(*recs[:per.value * cnt.value])
     l.deflateEnd(C.byref(s))
     print("deflate(): %d -> %d in %.1f ms = %.2f GB/s (host buffers, gzip wrapper)" % (n, total, dt * 1e3, n / dt / 1e9), flush=True)
-for it in range(4):
+for it in range(6):
     s = Z.ZStream()
     assert l.inflateInit2_(C.byref(s), 47, Z.VERSION, Z.SZ) == 0
     if it >= 2:
         assert l.zamd_inflate_index_hint(C.byref(s), index, len(index) // 2) == 0
+    if it >= 4:
+        assert l.zamd_inflate_index_hint_splits(C.byref(s), splits, per.value) == 0
     s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(out), total, C.addressof(back), n
     t0 = time.time()
     rc = l.inflate(C.byref(s), Z.Z_FINISH)
     dt = time.time() - t0
     assert rc == Z.Z_STREAM_END, (rc, s.msg)
     l.inflateEnd(C.byref(s))
-    print("inflate()%s: %.1f ms = %.2f GB/s of output (host buffers)" % (" with the chunk index" if it >= 2 else "", dt * 1e3, n / dt / 1e9), flush=True)
+    print("inflate()%s: %.1f ms = %.2f GB/s of output (host buffers)" % (" with the chunk index and its split points" if it >= 4 else " with the chunk index" if it >= 2 else "", dt * 1e3, n / dt / 1e9), flush=True)
 print("round trip", "OK" if back.raw == bytes(data) else "MISMATCH")

@@ -818,3 +818,65 @@ def test_overlapped_batches_equal_batches_in_a_row(monkeypatch, wbits, first_flu
     assert piped == plain and tot_p == tot_q and idx_a == idx_b
     assert small == plain and tot_s == tot_q
     assert pyz.decompressobj(wbits).decompress(piped) == data
+
+
+def test_inflate_places_large_rounds_in_overlapped_groups():
+    """With a chunk index that carries split points, a round of inflate() that can write straight into the caller's
+    buffer is placed in groups whose uploads and downloads overlap the next group's kernels.  ZAMD_Z_INF_GROUP_MIB=16
+    makes 16 MiB groups (read once per process, hence the child process): the bytes, the check value and the totals are
+    those of one pass; an index or split records that lie, and a stream that is damaged in a late group, behave as
+    they do without the groups."""
+    import subprocess, sys
+    code = r"""
+import ctypes as C, sys, zlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _zapi as Z, zlib_amd
+n = 100 << 20
+data = bytes(zlib_amd.corpus(n, 4, 31, piece_bytes=16 << 20, threads=8))
+idx, spl = [], []
+comp, totals = Z.deflate_stream(data, level=6, wbits=31, out_step=n + (1 << 20), index=idx, splits=spl)
+assert idx[0] == 0 and len(idx) - 1 == n >> 20
+pairs = idx[1:]
+per = spl[0]
+assert per == 7 and len(spl) - 1 == per * len(pairs) and sum(1 for r in spl[1:] if r) > 3 * len(pairs)
+l = Z.lib()
+def inflate_all(comp, hint, splits=None):
+    s = Z.ZStream()
+    assert l.inflateInit2_(C.byref(s), 47, Z.VERSION, Z.SZ) == 0
+    if hint is not None:
+        flat = (C.c_uint * (2 * len(hint)))(*[v for p in hint for v in p])
+        assert l.zamd_inflate_index_hint(C.byref(s), flat, len(hint)) == 0
+    if splits is not None:
+        recs = (C.c_ulonglong * (len(splits) - 1))(*splits[1:])
+        assert l.zamd_inflate_index_hint_splits(C.byref(s), recs, splits[0]) == 0
+    src = C.create_string_buffer(comp, len(comp)); back = C.create_string_buffer(n + 16)
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(comp), C.addressof(back), n + 16
+    rc = l.inflate(C.byref(s), Z.Z_FINISH)
+    out = (rc, back.raw[:s.total_out], s.msg, s.total_in, s.adler)
+    l.inflateEnd(C.byref(s))
+    return out
+for hint, splits in ((pairs, spl), (pairs, None), (None, None)):
+    rc, out, msg, tin, adler = inflate_all(comp, hint, splits)
+    assert rc == Z.Z_STREAM_END and out == data and tin == len(comp) and adler == zlib.crc32(data), (rc, msg, len(out))
+# an index whose chunk sizes are wrong from chunk 40 on: the chunks in front of it are placed by it, the rest without it
+lying = list(pairs); lying[40] = (lying[40][0] + 1, lying[40][1]); lying[41] = (lying[41][0] - 1, lying[41][1])
+rc, out, msg, tin, adler = inflate_all(comp, lying, spl)
+assert rc == Z.Z_STREAM_END and out == data and adler == zlib.crc32(data), (rc, msg)
+# split records that are no block boundaries (chunk 50), out of order (chunk 51) and outside their chunk (chunk 52)
+wrong = list(spl)
+wrong[1 + 50 * per] += 3 << 32
+wrong[1 + 51 * per], wrong[2 + 51 * per] = wrong[2 + 51 * per], wrong[1 + 51 * per]
+wrong[1 + 52 * per] = (0xfffffff0 << 32) | 77
+rc, out, msg, tin, adler = inflate_all(comp, pairs, wrong)
+assert rc == Z.Z_STREAM_END and out == data and adler == zlib.crc32(data), (rc, msg)
+# damaged data in chunk 70: what lies in front of it arrives, then the error (of the block, or of the check value at the end)
+bad = bytearray(comp); at = sum(p[0] for p in pairs[:70]) + 5000; bad[at] ^= 0x55
+for hint, splits in ((pairs, spl), (pairs, None), (None, None)):
+    rc, out, msg, tin, adler = inflate_all(bytes(bad), hint, splits)
+    assert rc == Z.Z_DATA_ERROR and msg, (rc, msg)
+    assert len(out) >= (60 << 20) and out[:60 << 20] == data[:60 << 20]
+print("ok")
+""" % (os.path.join(Z.ROOT, "tests"), Z.ROOT)
+    env = dict(os.environ, ZAMD_Z_INF_GROUP_MIB="16")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

@@ -1611,15 +1611,21 @@ __global__ void k_layout(ZkJob J)
     J.sync_bit[lc] = sync;
     if (call_end) J.err[3] = left;
     if (J.splits) {
-        /* where a reader may cut the chunk into split_parts parts of about the same output: for part k the first block
-         * that starts at or behind k / split_parts of the chunk's data, as (bit offset from the chunk's first byte) << 32 |
-         * offset of the block's first byte in the chunk's data; strictly ascending, packed to the front, zeros behind */
+        /* Where a reader may cut the chunk into split_parts parts that take about the same time to decode, which goes by
+         * symbols, not bytes (a block of literals and a block of long matches take the same): part k starts at the first
+         * block in front of which k / split_parts of the chunk's symbols lie (a stored block counts as one symbol per 64
+         * bytes).  A record is (bit offset from the chunk's first byte) << 32 | offset of the block's first byte in the
+         * chunk's data; strictly ascending, packed to the front, zeros behind. */
         uint64_t *sp = J.splits + (J.chunk0 + lc) * (uint64_t)(J.split_parts - 1u);
         const uint32_t nb = J.nblk[lc];
-        uint32_t j = 1, last_off = 0, w = 0;
+        auto weight = [&](uint32_t j) { return base[j].type == 0 ? base[j].in_len / 64u + 1u : base[j].sym_count + 1u; };
+        uint64_t total = 0;
+        for (uint32_t j = 0; j < nb; j++) total += weight(j);
+        uint32_t j = 0, last_off = 0, w = 0;
+        uint64_t before = 0;                                /* symbols in front of block j */
         for (uint32_t k = 1; k < J.split_parts; k++) {
-            const uint32_t target = g.dict_len + (uint32_t)((uint64_t)g.len * k / J.split_parts);
-            while (j < nb && base[j].in_start < target) j++;
+            const uint64_t target = total * k / J.split_parts;
+            while (j < nb && (before < target || j == 0)) { before += weight(j); j++; }
             if (j >= nb) break;
             const uint32_t off = base[j].in_start - g.dict_len;
             if (off > last_off && off < g.len) { sp[w++] = (base[j].bit_off << 32) | off; last_off = off; }

@@ -1076,9 +1076,9 @@ extern "C" int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uin
     HIPCHK(hipMemcpy(e->inf->d_segs, segs, nseg * sizeof(ZiSeg), hipMemcpyHostToDevice));
     /* every segment is reported, so a failing one is not an error of the call */
     int64_t bad = -1;
-    bool regular = segs[0].out_off == 0;   /* and every segment but the last at least 32 KiB long and back to back */
+    bool regular = segs[0].out_off == 0;   /* and the segments back to back, their lengths known beforehand */
     for (uint64_t i = 0; i + 1 < nseg && regular; i++)
-        regular = segs[i].out_cap >= 32768 && segs[i].out_off + segs[i].out_cap == segs[i + 1].out_off && (segs[i].mode & ZAMD_INF_EXACT);
+        regular = segs[i].out_off + segs[i].out_cap == segs[i + 1].out_off && (segs[i].mode & ZAMD_INF_EXACT);
     rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad, regular);
     if (rc != ZAMD_OK && rc != ZAMD_DATA_ERROR) return rc;
     HIPCHK(hipMemcpy(segs, e->inf->d_segs, nseg * sizeof(ZiSeg), hipMemcpyDeviceToHost));

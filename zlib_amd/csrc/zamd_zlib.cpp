@@ -127,6 +127,7 @@ typedef std::vector<uint64_t, ZAlloc<uint64_t>> Longs;
 const uint32_t DEFLATE_MAGIC = 0x5a414d44u;   // distinguishes our states from inflate states
 const uint32_t INFLATE_MAGIC = 0x5a414d49u;
 const uint32_t HIST = 32768;
+const uint32_t IDX_PARTS = 8;                 // parts a chunk of the index can be cut into: IDX_PARTS - 1 split records per chunk
 
 struct Trace {      // ZAMD_Z_TRACE=1: phase times of every engine round trip on stderr
     bool on; std::chrono::steady_clock::time_point t; std::string line;
@@ -160,7 +161,9 @@ struct DState {
     size_t out_pos;
     bool index_on, index_ok;           // chunk index wanted (zamd_deflate_index); still describes the whole stream
     Words index;                       // per chunk since the last reset: compressed bytes, inflated bytes
-    explicit DState(z_streamp strm) : hist(ZAlloc<uint8_t>(strm)), in(ZAlloc<uint8_t>(strm)), out(ZAlloc<uint8_t>(strm)), index(ZAlloc<uint32_t>(strm)) {}
+    Longs splits;                      // and IDX_PARTS - 1 split records (block boundaries inside the chunk, zamd_engine_splits)
+    explicit DState(z_streamp strm) : hist(ZAlloc<uint8_t>(strm)), in(ZAlloc<uint8_t>(strm)), out(ZAlloc<uint8_t>(strm)), index(ZAlloc<uint32_t>(strm)),
+                                      splits(ZAlloc<uint64_t>(strm)) {}
 };
 
 inline DState *dstate(z_streamp strm) {
@@ -282,30 +285,34 @@ int batch_compute(z_streamp strm, DState *s, zamd_engine *e, Batch &b, Trace &tr
     // everything that can fail without the engine comes first: the engine is shared by all streams, and what is set on
     // it below is one-shot state that the call which follows must consume
     if (s->index_on && s->index_ok && !odd_tail) {
-        if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, (nch + 1) * 8 > HIST ? (nch + 1) * 8 : HIST) != Z_OK) return ZAMD_MEM_ERROR;
+        const uint64_t tab_bytes = (nch + 1) * 8 + nch * (IDX_PARTS - 1) * 8;      // offsets, then the split records
+        if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, tab_bytes > HIST ? tab_bytes : HIST) != Z_OK) return ZAMD_MEM_ERROR;
         d_tab = g_gpu.d_off;
     }
     struct EngineReset {       // whatever happens below, the next stream finds the engine as it expects it
         zamd_engine *e;
-        ~EngineReset() { zamd_engine_tune(e, 0, 0, 0, 0); zamd_engine_window_bits(e, 15); zamd_engine_prime(e, 0, 0); zamd_engine_tail(e, ZAMD_TAIL_SYNC); }
+        ~EngineReset() { zamd_engine_tune(e, 0, 0, 0, 0); zamd_engine_window_bits(e, 15); zamd_engine_prime(e, 0, 0); zamd_engine_tail(e, ZAMD_TAIL_SYNC);
+                         zamd_engine_splits(e, nullptr, 0); }
     } engine_reset = {e};
     const uint32_t prime_bits = s->prime_bits, prime_val = s->prime_val;
     if (s->tuned) rc = zamd_engine_tune(e, s->tune[0], s->tune[1], s->tune[2], s->tune[3]);
     if (rc == 0) rc = zamd_engine_window_bits(e, s->w_bits);
     if (rc == 0 && prime_bits) rc = zamd_engine_prime(e, (int)prime_bits, (int)prime_val);
     if (rc == 0 && odd_tail) { rc = zamd_engine_tail(e, b.tail); s->index_ok = false; }
+    if (rc == 0 && d_tab) rc = zamd_engine_splits(e, d_tab + nch + 1, IDX_PARTS);
     if (rc == 0)
         rc = zamd_deflate_shard_dev(e, d_in + HIST, n, b.head, s->chunk_size, s->level, s->strategy,
                                     s->mem_level, b.finish, d_out, b.bound, d_tab, &b.total);
     if (rc == 0 && d_tab) {
         // chunks end on byte boundaries (a sync marker or the final block), so byte counts describe them
-        std::vector<uint64_t> off(nch + 1);
-        rc = zamd_dev_download(e, off.data(), d_tab, (nch + 1) * 8);
+        std::vector<uint64_t> off(nch + 1 + nch * (IDX_PARTS - 1));
+        rc = zamd_dev_download(e, off.data(), d_tab, off.size() * 8);
         for (uint64_t c = 0; rc == 0 && c < nch; c++) {
             const uint64_t raw = n ? ((c + 1) * s->chunk_size <= n ? s->chunk_size : n - c * s->chunk_size) : 0;
             s->index.push_back((uint32_t)(off[c + 1] - off[c]));
             s->index.push_back((uint32_t)raw);
         }
+        if (rc == 0) s->splits.insert(s->splits.end(), off.begin() + nch + 1, off.end());
     }
     if (rc == 0) {
         // the stream's pending bits went out in front of this call's first chunk; the bits behind the call's last whole
@@ -584,7 +591,7 @@ int deflateResetKeep(z_streamp strm) {
     s->trailer_done = false;
     s->have_dict = false; s->dictid = 0;
     s->prime_bits = 0; s->prime_val = 0;
-    s->index.clear(); s->index_ok = true;
+    s->index.clear(); s->splits.clear(); s->index_ok = true;
     return Z_OK;
 }
 
@@ -825,7 +832,16 @@ int zamd_deflate_index(z_streamp strm, int enable) {
     if (!s) return Z_STREAM_ERROR;
     if (s->since_reset != 0 || !s->in.empty()) return Z_STREAM_ERROR;     // before the first input only
     s->index_on = enable != 0;
-    s->index.clear(); s->index_ok = true;
+    s->index.clear(); s->splits.clear(); s->index_ok = true;
+    return Z_OK;
+}
+int zamd_deflate_index_splits(z_streamp strm, const unsigned long long **recs, unsigned *per_chunk) {
+    DState *s = dstate(strm);
+    if (!s || !recs || !per_chunk) return Z_STREAM_ERROR;
+    if (!s->index_on) return Z_STREAM_ERROR;
+    if (!s->index_ok || s->splits.size() != s->index.size() / 2 * (IDX_PARTS - 1)) return Z_DATA_ERROR;
+    static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "split records are 64 bits wide");
+    *recs = (const unsigned long long *)s->splits.data(); *per_chunk = IDX_PARTS - 1;
     return Z_OK;
 }
 int zamd_deflate_index_get(z_streamp strm, const unsigned **pairs, unsigned *n_chunks) {
@@ -865,9 +881,10 @@ struct IState {
     uint64_t out_batch;
     uint64_t prime_hold; unsigned prime_bits;   // inflatePrime bits waiting in front of the first input byte
     Words hints; size_t hint_pos;   // chunk index of the deflate data ahead (zamd_inflate_index_hint): compressed bytes, inflated bytes per chunk
+    Longs hint_splits; unsigned hint_per;   // and hint_per split records per chunk (zamd_inflate_index_hint_splits), or none
     size_t call_taken;              // bytes the current inflate() call has moved from next_in to the end of `in`
     explicit IState(z_streamp strm) : hdr(ZAlloc<uint8_t>(strm)), in(ZAlloc<uint8_t>(strm)), cands(ZAlloc<uint64_t>(strm)), out(ZAlloc<uint8_t>(strm)),
-                                      hist(ZAlloc<uint8_t>(strm)), hints(ZAlloc<uint32_t>(strm)) {}
+                                      hist(ZAlloc<uint8_t>(strm)), hints(ZAlloc<uint32_t>(strm)), hint_splits(ZAlloc<uint64_t>(strm)), hint_per(0) {}
 };
 
 // Hands the bytes at the end of `in` that the current call took (at most `want` of them) back to the caller.
@@ -985,11 +1002,133 @@ void idrain(z_streamp strm, IState *s) {
     if (s->out_pos == s->out.size()) { s->out.clear(); s->out_pos = 0; }
 }
 
+// Places the segments of `chain` (ZAMD_INF_EXACT, their outputs back to back from offset 0) straight into the caller's
+// buffer in groups of about `group_out` bytes of output: while the GPU decodes group k, one helper thread downloads
+// group k - 1 and (when the compressed data is not on the device yet: `d_comp` null) another uploads the input of
+// group k + 1.  The window in front of a group is the end of the group before it, still on the device.  `good` receives
+// the number of leading segments that were placed, verified and downloaded; a segment that does not end where and as it
+// should stops the row there (the caller decides what that means).  Returns 0, or the engine's error code.
+int place_piped(zamd_engine *e, IState *s, const uint8_t *ip, size_t in_n, const uint8_t *d_comp, std::vector<zamd_inflate_seg> &chain,
+                uint8_t *dst, uint64_t group_out, size_t *good, uint32_t *bad_status, Trace &tr) {
+    struct Grp { size_t s0, s1; uint64_t out_off, out_len, in0, in_len; };
+    std::vector<Grp> gs;
+    for (size_t i = 0; i < chain.size();) {
+        Grp g; g.s0 = i; g.out_off = chain[i].out_off; g.out_len = 0;
+        while (i < chain.size() && (g.out_len < group_out || chain.size() - i < 2)) { g.out_len += chain[i].out_cap; i++; }
+        g.s1 = i;
+        g.in0 = chain[g.s0].in_bit >> 3; g.in_len = ((chain[g.s1 - 1].in_end_bit + 7) >> 3) - g.in0;
+        gs.push_back(g);
+    }
+    *good = 0; *bad_status = 0;
+    const size_t ng = gs.size();
+    uint64_t max_in = 0, max_out = 0;
+    for (const Grp &g : gs) { if (g.in_len > max_in) max_in = g.in_len; if (g.out_len > max_out) max_out = g.out_len; }
+    for (int k = 0; k < 2; k++) {
+        if (!d_comp && grow(e, &slot_in(k), &slot_in_cap(k), max_in + 64) != Z_OK) return ZAMD_MEM_ERROR;
+        if (grow(e, &slot_out(k), &slot_out_cap(k), max_out + 64) != Z_OK) return ZAMD_MEM_ERROR;
+    }
+    uint8_t *d_head0 = nullptr;
+    if (!s->hist.empty()) {
+        if (grow(e, (uint8_t **)&g_gpu.d_off, &g_gpu.off_cap, HIST) != Z_OK) return ZAMD_MEM_ERROR;
+        d_head0 = (uint8_t *)g_gpu.d_off;
+        if (zamd_dev_upload(e, d_head0 + (HIST - s->hist.size()), s->hist.data(), s->hist.size()) != 0) return ZAMD_MEM_ERROR;
+    }
+    std::mutex mu; std::condition_variable cv;
+    size_t uploaded = d_comp ? ng : 0, computed = 0, downloaded = 0;
+    int err = 0;
+    std::thread up, down;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::vector<double> t_up(ng, 0), t_comp0(ng, 0), t_comp(ng, 0), t_down0(ng, 0), t_down(ng, 0);      // ZAMD_Z_TRACE: when each step of each group ended
+    std::vector<double> t_dec(ng, 0), t_res(ng, 0), t_seg(ng, 0);
+    struct Joiner {            // whatever happens, the helpers are told to stop and joined before their captures go away
+        std::thread &a, &b; std::mutex &mu; std::condition_variable &cv; int &err; size_t &computed; size_t ng;
+        ~Joiner() {
+            { std::lock_guard<std::mutex> g(mu); if (computed < ng && !err) err = ZAMD_STREAM_ERROR; }
+            cv.notify_all();
+            if (a.joinable()) a.join();
+            if (b.joinable()) b.join();
+        }
+    } joiner = {up, down, mu, cv, err, computed, ng};
+    if (!d_comp)
+        up = std::thread([&] {
+            for (size_t k = 0; k < ng; k++) {
+                { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || computed + 2 > k; }); if (err) return; }
+                int rc = zamd_dev_upload_staged(e, slot_in((int)(k & 1)), ip + gs[k].in0, gs[k].in_len);
+                t_up[k] = now_ms();
+                { std::lock_guard<std::mutex> g(mu); if (rc) err = err ? err : rc; uploaded = k + 1; }
+                cv.notify_all();
+                if (rc) return;
+            }
+        });
+    down = std::thread([&] {
+        for (size_t k = 0; k < ng; k++) {
+            { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || computed > k; }); if (computed <= k) return; }
+            t_down0[k] = now_ms();
+            int rc = zamd_dev_download_staged(e, dst + gs[k].out_off, slot_out((int)(k & 1)), gs[k].out_len);
+            t_down[k] = now_ms();
+            { std::lock_guard<std::mutex> g(mu); if (rc) err = err ? err : rc; downloaded = k + 1; }
+            cv.notify_all();
+            if (rc) return;
+        }
+    });
+    std::vector<zamd_inflate_seg> segs;
+    size_t verified = 0;
+    for (size_t k = 0; k < ng; k++) {
+        { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || (uploaded > k && downloaded + 2 > k); }); if (err) break; }
+        const Grp &g = gs[k];
+        t_comp0[k] = now_ms();
+        segs.assign(chain.begin() + g.s0, chain.begin() + g.s1);
+        const uint64_t bit0 = d_comp ? 0 : g.in0 * 8;
+        for (zamd_inflate_seg &q : segs) { q.in_bit -= bit0; q.in_end_bit -= bit0; q.out_off -= g.out_off; }
+        const uint8_t *d_head = k == 0 ? d_head0 : slot_out((int)((k - 1) & 1)) + gs[k - 1].out_len - HIST;
+        uint8_t *d_out = slot_out((int)(k & 1));
+        int rc = zamd_inflate_segments_dev(e, d_comp ? d_comp : slot_in((int)(k & 1)), d_comp ? in_n : g.in_len, segs.data(), segs.size(), d_head, d_out, g.out_len);
+        t_seg[k] = now_ms();
+        { int nl = 0; t_dec[k] = zamd_last_timing_ms(e, 7, &nl); t_res[k] = zamd_last_timing_ms(e, 8, &nl); }
+        bool fits = rc == 0;
+        for (size_t i = 0; fits && i < segs.size(); i++) {
+            if (segs[i].status >= 3) { *bad_status = segs[i].status; fits = false; }
+            if (segs[i].status == 1 && !(k + 1 == ng && i + 1 == segs.size())) { *bad_status = 1; fits = false; }     // the final block may only close the last segment
+        }
+        if (fits) for (size_t i = 0; i < segs.size(); i++) { chain[g.s0 + i].status = segs[i].status; chain[g.s0 + i].end_bit = segs[i].end_bit + bit0; }
+        if (fits && s->wrap) {
+            uint32_t v = s->check;
+            rc = s->gzip ? zamd_crc32_dev(e, v, d_out, g.out_len, &v) : zamd_adler32_dev(e, v, d_out, g.out_len, &v);
+            if (rc == 0) s->check = v;
+        }
+        t_comp[k] = now_ms();
+        { std::lock_guard<std::mutex> g2(mu); if (rc) err = err ? err : rc; else if (fits) computed = k + 1; }
+        cv.notify_all();
+        if (rc || !fits) break;
+        verified = g.s1;
+    }
+    { std::lock_guard<std::mutex> g(mu); if (computed < ng && !err) err = 1; }     // 1: stop, nothing wrong with the GPU
+    cv.notify_all();
+    if (up.joinable()) up.join();
+    if (down.joinable()) down.join();
+    tr.lap("place+download, pipelined");
+    if (tr.on) {
+        char b[200];
+        for (size_t k = 0; k < ng; k++) {
+            snprintf(b, sizeof b, " [g%zu up %.0f kern %.0f-%.0f (segments call until %.0f: decode %.1f resolve %.1f) down %.0f-%.0f]", k, t_up[k], t_comp0[k], t_comp[k],
+                     t_seg[k], t_dec[k], t_res[k], t_down0[k], t_down[k]);
+            tr.line += b;
+        }
+    }
+    if (err && err != 1) return err;
+    // what counts is what has arrived in the caller's buffer
+    *good = downloaded >= ng ? verified : (downloaded ? gs[downloaded - 1].s1 : 0);
+    if (*good > verified) *good = verified;
+    return 0;
+}
+
 // One decode attempt over the buffered input, or, with `ext`, over the caller's own input buffer
 // (nothing is buffered then: what the attempt consumes is taken off next_in, the rest stays with the
 // caller).  Returns Z_OK (with or without progress), NO_PROGRESS (ext only: not one whole block in
 // there), Z_DATA_ERROR (msg set) or Z_MEM_ERROR.
 const int NO_PROGRESS = 100, HINT_MISFIT = 101;
+inline void drop_hints(IState *s) { s->hints.clear(); s->hint_pos = 0; s->hint_splits.clear(); s->hint_per = 0; }
 int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t ext_n = 0) {
     const bool view = ext != nullptr;
     const uint8_t *const ip = view ? ext : s->in.data();
@@ -1002,9 +1141,17 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     std::lock_guard<std::mutex> lk(g_gpu.mu);
     zamd_engine *e = engine_locked();
     if (!e) return Z_MEM_ERROR;
-    if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, in_n + 64) != Z_OK) return Z_MEM_ERROR;
-    if (zamd_dev_upload(e, g_gpu.d_in, ip, in_n) != 0) return Z_MEM_ERROR;
-    tr.lap("upload");
+    // the input goes to the device when somebody needs it there: a round that places chunks by their index in
+    // overlapped groups uploads group by group
+    bool on_device = false;
+    auto need_input = [&]() -> int {
+        if (on_device) return Z_OK;
+        if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, in_n + 64) != Z_OK) return Z_MEM_ERROR;
+        if ((in_n >= (32u << 20) ? zamd_dev_upload_staged : zamd_dev_upload)(e, g_gpu.d_in, ip, in_n) != 0) return Z_MEM_ERROR;
+        on_device = true;
+        tr.lap("upload");
+        return Z_OK;
+    };
     const uint64_t end_bits = in_n * 8ull;
     // what a round may produce: the output batch, or what the caller's buffer takes when the round can write straight into it
     uint64_t out_batch = s->out_batch;
@@ -1017,16 +1164,32 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     // the attempt starts over without it.
     bool hinted = false;
     size_t hints_used = 0;
+    std::vector<uint32_t> chunk_end;        // hinted: chain[chunk_end[k] - 1] is the last segment of the k-th chunk taken
     if (s->hint_pos < s->hints.size() && s->bit_off == 0) {
         uint64_t pos = 0;
-        for (size_t h = s->hint_pos; h + 1 < s->hints.size() && chain.size() < 8192; h += 2) {
+        const unsigned per = s->hint_splits.size() == s->hints.size() / 2 * s->hint_per ? s->hint_per : 0u;
+        for (size_t h = s->hint_pos; h + 1 < s->hints.size() && chunk_end.size() < 8192 && chain.size() + per + 1 <= 32768; h += 2) {
             const uint64_t clen = s->hints[h], raw = s->hints[h + 1];
             if (raw == 0 || pos + clen > in_n || (produced + raw > out_batch && !chain.empty())) break;
-            zamd_inflate_seg g; memset(&g, 0, sizeof g);
-            g.in_bit = pos * 8; g.in_end_bit = (pos + clen) * 8; g.out_off = produced; g.out_cap = raw; g.out_len = raw;
-            g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
-            g.mode = ZAMD_INF_EXACT;
-            chain.push_back(g);
+            // the chunk's split records cut it into parts, one wavefront each; a record that is out of order or outside
+            // the chunk ends the chunk's list (one that is no block boundary shows when its part does not decode)
+            uint64_t pbit = pos * 8, pout = 0;
+            auto part = [&](uint64_t bit_end, uint64_t out_end) {
+                zamd_inflate_seg g; memset(&g, 0, sizeof g);
+                g.in_bit = pbit; g.in_end_bit = bit_end; g.out_off = produced + pout; g.out_cap = out_end - pout; g.out_len = g.out_cap;
+                g.win_avail = (uint32_t)((s->hist.size() + g.out_off) < HIST ? (s->hist.size() + g.out_off) : HIST);
+                g.mode = ZAMD_INF_EXACT;
+                chain.push_back(g);
+                pbit = bit_end; pout = out_end;
+            };
+            for (unsigned k = 0; k < per; k++) {
+                const uint64_t rec = s->hint_splits[h / 2 * per + k];
+                const uint64_t bit = pos * 8 + (rec >> 32), off = rec & 0xffffffffull;
+                if (rec == 0 || off <= pout || off >= raw || bit <= pbit || bit >= (pos + clen) * 8) break;
+                part(bit, off);
+            }
+            part((pos + clen) * 8, raw);
+            chunk_end.push_back((uint32_t)chain.size());
             pos += clen; produced += raw; hints_used += 2;
         }
         hinted = !chain.empty();
@@ -1037,9 +1200,10 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
             s->tried = in_n;
             return Z_OK;
         }
-        else { s->hints.clear(); s->hint_pos = 0; }         // an empty or oversized chunk: the general path takes over
+        else { drop_hints(s); }         // an empty or oversized chunk: the general path takes over
     }
     if (!hinted) {
+        if (need_input() != Z_OK) return Z_MEM_ERROR;
         // sync-marker candidates: independent starting points for parallel wavefronts.  The bytes that are
         // new since the last attempt are searched on the GPU (a marker may straddle the old end).
         {
@@ -1187,10 +1351,51 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         }
     }
     if (chain.empty()) { if (view) return NO_PROGRESS; s->tried = in_n; return Z_OK; }
-    if (!hinted) { s->hints.clear(); s->hint_pos = 0; }      // progress off the chunk grid: an index no longer applies
+    if (!hinted) { drop_hints(s); }      // progress off the chunk grid: an index no longer applies
     tr.lap("chain");
 
-    if (produced) {
+    // Large rounds of indexed chunks that come with split points and can go straight into the caller's buffer are placed in
+    // groups whose transfers overlap the next group's kernels (place_piped), their input uploaded group by group as well.
+    // (A group's kernels take as long as its slowest segment: whole chunks, at some 60 ms each, make groups a loss.)
+    static const uint64_t group_out = env_u64("ZAMD_Z_INF_GROUP_MIB", 512) << 20;
+    const bool piped = hinted && s->hint_per && produced >= 2 * group_out && chain.size() >= 2 && s->out.size() == s->out_pos && strm->avail_out >= produced &&
+                       group_out >= HIST && !getenv("ZAMD_Z_NO_PIPELINE");
+    if (produced && piped) {
+        size_t good = 0; uint32_t bad = 0;
+        const uint32_t check0 = s->check;
+        int rc = place_piped(e, s, ip, in_n, on_device ? g_gpu.d_in : nullptr, chain, strm->next_out, group_out, &good, &bad, tr);
+        if (rc != 0) { s->check = check0; return Z_MEM_ERROR; }
+        if (good == 0) {
+            if (hinted) { drop_hints(s); return HINT_MISFIT; }
+            return ibad(strm, s, zamd_inflate_message(bad));
+        }
+        if (good < chain.size()) {
+            // what lies in front of the failure is delivered (with an index: the whole chunks in front of it); the failure
+            // comes back on the next attempt, without the index should it be the index that did not fit
+            if (hinted) {
+                size_t k = 0;
+                while (k < chunk_end.size() && chunk_end[k] <= good) k++;
+                if (k == 0) { drop_hints(s); return HINT_MISFIT; }
+                good = chunk_end[k - 1];
+                hints_used = 2 * k;
+                s->hints.resize(s->hint_pos + hints_used);
+                if (s->hint_per) s->hint_splits.resize((s->hint_pos + hints_used) / 2 * s->hint_per);
+            }
+            chain.resize(good);
+            final_block = false;
+        }
+        produced = chain.back().out_off + chain.back().out_cap;
+        end_bit = hinted ? chain.back().in_end_bit : chain.back().end_bit;
+        if (good == chain.size() && chain.back().status == 1) final_block = true;
+        if (hinted) s->hint_pos += hints_used;
+        if (s->wrap) strm->adler = s->check;
+        const uint8_t *got = strm->next_out;
+        strm->next_out += produced; strm->avail_out -= (uInt)produced; strm->total_out += produced;
+        s->total += produced;
+        const size_t wlim = s->wbits >= 8 && s->wbits < 15 ? (size_t)1 << s->wbits : HIST;
+        s->hist.assign(got + produced - wlim, got + produced);
+    } else if (produced) {
+        if (need_input() != Z_OK) return Z_MEM_ERROR;
         if (grow(e, &g_gpu.d_out, &g_gpu.out_cap, produced + 64) != Z_OK) return Z_MEM_ERROR;
         uint8_t *d_head = nullptr;
         if (!s->hist.empty()) {
@@ -1202,13 +1407,13 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
             return Z_MEM_ERROR;
         for (const zamd_inflate_seg &g : chain)
             if (g.status >= 3) {
-                if (hinted) { s->hints.clear(); s->hint_pos = 0; return HINT_MISFIT; }
+                if (hinted) { drop_hints(s); return HINT_MISFIT; }
                 return ibad(strm, s, zamd_inflate_message(g.status));
             }
         if (hinted) {
             // the final block may only close the last chunk taken
             for (size_t i = 0; i + 1 < chain.size(); i++)
-                if (chain[i].status == 1) { s->hints.clear(); s->hint_pos = 0; return HINT_MISFIT; }
+                if (chain[i].status == 1) { drop_hints(s); return HINT_MISFIT; }
             final_block = chain.back().status == 1;
             s->hint_pos += hints_used;
         }
@@ -1271,7 +1476,7 @@ int istate_reset(z_streamp strm, IState *s, bool keep_window) {
     s->hdr.clear(); s->in.clear(); s->cands.clear(); s->out.clear();
     s->bit_off = 0; s->scanned = 0; s->tried = 0; s->out_pos = 0; s->check = 0; s->dictid = 0;
     s->prime_hold = 0; s->prime_bits = 0;
-    s->hints.clear(); s->hint_pos = 0;
+    drop_hints(s);
     if (!keep_window) s->hist.clear();
     return Z_OK;
 }
@@ -1459,9 +1664,20 @@ static int zamd_inflate_index_hint_body(z_streamp strm, const unsigned *pairs, u
     if (s->mode != IM_HEAD && !(s->mode == IM_BODY && s->total == 0 && s->in.empty())) return Z_STREAM_ERROR;
     s->hints.assign(pairs, pairs + 2 * (size_t)n_chunks);
     s->hint_pos = 0;
+    s->hint_splits.clear(); s->hint_per = 0;
     return Z_OK;
 }
 int zamd_inflate_index_hint(z_streamp strm, const unsigned *pairs, unsigned n_chunks) { return guarded(strm, [&] { return zamd_inflate_index_hint_body(strm, pairs, n_chunks); }); }
+// The split records that go with the index just given (zamd_deflate_index_splits): per_chunk records for each of its chunks.
+static int zamd_inflate_index_hint_splits_body(z_streamp strm, const unsigned long long *recs, unsigned per_chunk) {
+    IState *s = istate(strm);
+    if (!s || recs == Z_NULL || per_chunk == 0 || per_chunk > 15) return Z_STREAM_ERROR;
+    if (s->hints.empty() || s->hint_pos != 0 || s->total != 0) return Z_STREAM_ERROR;
+    s->hint_splits.assign((const uint64_t *)recs, (const uint64_t *)recs + s->hints.size() / 2 * per_chunk);
+    s->hint_per = per_chunk;
+    return Z_OK;
+}
+int zamd_inflate_index_hint_splits(z_streamp strm, const unsigned long long *recs, unsigned per_chunk) { return guarded(strm, [&] { return zamd_inflate_index_hint_splits_body(strm, recs, per_chunk); }); }
 
 int inflateGetDictionary(z_streamp strm, Bytef *dictionary, uInt *dictLength) {
     IState *s = istate(strm);
