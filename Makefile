@@ -1,13 +1,13 @@
 # Builds the product library (HIP, gfx950) and the test-side oracle.
 HIPCC ?= hipcc
 ARCH ?= gfx950
-SRCS = zlib_amd/csrc/zamd_engine.hip zlib_amd/csrc/zamd_corpus.cpp
+SRCS = zlib_amd/csrc/zamd_engine.hip zlib_amd/csrc/zamd_corpus.cpp zlib_amd/csrc/zamd_multi.cpp
 HDRS = zlib_amd/csrc/zamd_core.h zlib_amd/csrc/zamd_inflate_impl.h zlib_amd/csrc/zamd_fast_impl.h zlib_amd/csrc/zamd_follow_impl.h include/zamd.h
 
 all: zlib_amd/libzamd.so zlib_amd/libzamd_z.so examples/zamd_gzip oracle
 
 zlib_amd/libzamd.so: $(SRCS) $(HDRS)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -o $@ $(SRCS)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -o $@ $(SRCS) -ldl
 
 # The reference's symbol versions (programs linked against a versioned libz find their symbols when this library is
 # preloaded or linked in its place).  The SONAME stays libzamd_z.so on purpose: under the name libz.so.1 the loader would
@@ -33,4 +33,4 @@ clean:
 
 # the parse-following matcher with its counters compiled in (tests/gpu_spec_stats.py)
 zlib_amd/libzamd_stats.so: $(SRCS) $(HDRS)
-	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -DZAMD_SPEC_STATS -o $@ $(SRCS)
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -pthread -Wno-unused-value -Wno-unused-result -DZAMD_SPEC_STATS -o $@ $(SRCS) -ldl

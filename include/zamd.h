@@ -282,6 +282,46 @@ void zamd_corpus_fill_pieces(uint8_t *buf, uint64_t n, int kind, uint64_t seed, 
  * side all-gather their chunks' lengths (d_chunk_off[i + 1] - d_chunk_off[i] of their own calls) and scan them here. */
 int zamd_chunk_offsets_dev(zamd_engine *e, const uint64_t *d_lengths, uint64_t n, uint64_t base, uint64_t *d_offsets);
 
+/* The lengths that go into that scan, from a call's own offsets: d_lengths[i] = d_offsets[i + 1] - d_offsets[i] for
+ * i < n, and 0 for n <= i < pad_to (ranks contribute equally many entries to an all-gather; the ones that hold fewer
+ * chunks pad with chunks of no bytes, which the scan passes over). */
+int zamd_chunk_lengths_dev(zamd_engine *e, const uint64_t *d_offsets, uint64_t n, uint64_t *d_lengths, uint64_t pad_to);
+
+/*
+ * One deflate call on several GPUs of one node, one process: no counterpart in the reference, whose deflate() is one
+ * thread (deflate.c:665-976).  zamd_multi_create makes one engine per entry of `devices`; the input is cut into
+ * contiguous ranges of chunks (zamd_multi_partition), each range primed with the 32 KiB of input in front of it, and
+ * the ranges' outputs laid end to end are byte for byte the single-device stream.  The devices exchange the chunks'
+ * compressed lengths with ncclAllGather (librccl.so, opened at run time; one communicator per device through
+ * ncclCommInitAll) and every device scans the table (zamd_chunk_offsets_dev).  Without librccl, with ZAMD_NO_RCCL set,
+ * or with a device listed twice (RCCL refuses that), the lengths go through host memory and the host scans them
+ * (zamd_multi_offsets_host): zamd_multi_uses_rccl tells which.
+ */
+typedef struct zamd_multi zamd_multi;
+int zamd_multi_create(zamd_multi **out, const int *devices, int n_devices, uint64_t workspace_bytes_per_device);
+void zamd_multi_destroy(zamd_multi *m);
+int zamd_multi_devices(zamd_multi *m);
+zamd_engine *zamd_multi_engine(zamd_multi *m, int index);          /* e.g. for zamd_engine_tune on every device */
+int zamd_multi_uses_rccl(zamd_multi *m);
+/* Device `index` of n_devices takes chunks [*first, *first + *count) of total_chunks: *per_device = ceil(total /
+ * n_devices) chunks each, in device order, the last devices fewer or none.  In a table of n_devices * per_device
+ * entries laid out device after device, chunk c is then entry c and the padding lies behind the last chunk. */
+int zamd_multi_partition(uint64_t total_chunks, int n_devices, int index, uint64_t *first, uint64_t *count, uint64_t *per_device);
+int zamd_multi_offsets_host(const uint64_t *lengths, uint64_t n, uint64_t base, uint64_t *offsets);
+/* Ranges that are on their devices already: device i holds n[i] bytes (the partition's share) at d_in[i], with
+ * head_len[i] bytes of the input in front of them, and writes its part of the stream to d_out[i].  d_table[i] (on
+ * device i, n_devices * per_device + 1 entries) receives the place of EVERY chunk in the whole stream, h_table (host,
+ * may be NULL) the same; device i's bytes belong at table[i * per_device]. */
+int zamd_deflate_multi_dev(zamd_multi *m, const void *const *d_in, const uint64_t *n, const uint32_t *head_len, uint32_t chunk_size,
+                           int level, int strategy, int mem_level, int finish, void *const *d_out, const uint64_t *out_cap,
+                           uint64_t *const *d_table, uint64_t *h_table, uint64_t *total_out);
+/* The same from host memory to host memory (what deflate() of zamd_zlib.h calls when ZAMD_DEVICES names more than one
+ * device): h_dict / dict_len is the input in front of h_in (at most 32768 bytes), h_chunk_off (may be NULL) receives
+ * total_chunks + 1 offsets, *adler / *crc (may be NULL) are continued over h_in as adler32() / crc32() would. */
+int zamd_deflate_multi(zamd_multi *m, const void *h_in, uint64_t n, const void *h_dict, uint32_t dict_len, uint32_t chunk_size,
+                       int level, int strategy, int mem_level, int finish, void *h_out, uint64_t out_cap,
+                       uint64_t *h_chunk_off, uint64_t *total_out, uint32_t *adler, uint32_t *crc);
+
 /* `fn(arg)` is called from inside every following deflate call of this engine, on the calling thread, when the call's last
  * kernel has been queued and before the call starts to wait for the GPU (NULL: no call).  A copy between pageable host
  * memory and the device holds a lock of the GPU runtime for its whole length, and kernel launches of other threads

@@ -130,6 +130,25 @@ def load_library() -> C.CDLL:
     lib.zamd_dev_memset.restype = i32
     lib.zamd_version.argtypes = []
     lib.zamd_version.restype = C.c_char_p
+    lib.zamd_chunk_lengths_dev.argtypes = [vp, vp, u64, vp, u64]
+    lib.zamd_chunk_lengths_dev.restype = i32
+    lib.zamd_multi_create.argtypes = [C.POINTER(vp), C.POINTER(i32), i32, u64]
+    lib.zamd_multi_create.restype = i32
+    lib.zamd_multi_destroy.argtypes = [vp]
+    lib.zamd_multi_destroy.restype = None
+    lib.zamd_multi_devices.argtypes = [vp]
+    lib.zamd_multi_devices.restype = i32
+    lib.zamd_multi_engine.argtypes = [vp, i32]
+    lib.zamd_multi_engine.restype = vp
+    lib.zamd_multi_uses_rccl.argtypes = [vp]
+    lib.zamd_multi_uses_rccl.restype = i32
+    lib.zamd_multi_partition.argtypes = [u64, i32, i32, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    lib.zamd_multi_partition.restype = i32
+    lib.zamd_multi_offsets_host.argtypes = [C.POINTER(u64), u64, u64, C.POINTER(u64)]
+    lib.zamd_multi_offsets_host.restype = i32
+    lib.zamd_deflate_multi.argtypes = [vp, vp, u64, vp, u32, u32, i32, i32, i32, i32, vp, u64, C.POINTER(u64), C.POINTER(u64),
+                                       C.POINTER(u32), C.POINTER(u32)]
+    lib.zamd_deflate_multi.restype = i32
     _lib = lib
     return lib
 
@@ -199,6 +218,60 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def multi_partition(total_chunks: int, n_devices: int, index: int) -> Tuple[int, int, int]:
+    """(first chunk, chunk count, chunks per device) of device `index` (zamd_multi_partition; needs no GPU)."""
+    lib = load_library()
+    first, count, per = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _chk(lib.zamd_multi_partition(total_chunks, n_devices, index, C.byref(first), C.byref(count), C.byref(per)), "zamd_multi_partition")
+    return first.value, count.value, per.value
+
+
+def multi_offsets_host(lengths, base: int = 0) -> List[int]:
+    """Exclusive scan of chunk lengths on the host (zamd_multi_offsets_host; needs no GPU): len(lengths) + 1 offsets."""
+    lib = load_library()
+    n = len(lengths)
+    src = (C.c_uint64 * max(n, 1))(*lengths)
+    dst = (C.c_uint64 * (n + 1))()
+    _chk(lib.zamd_multi_offsets_host(src, n, base, dst), "zamd_multi_offsets_host")
+    return list(dst)
+
+
+class MultiEngine:
+    """One deflate call on several GPUs of this node (zamd_multi_create): one engine per entry of `devices`."""
+
+    def __init__(self, devices, workspace_bytes: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        arr = (C.c_int32 * len(devices))(*devices)
+        _chk(self.lib.zamd_multi_create(C.byref(h), arr, len(devices), workspace_bytes), "zamd_multi_create")
+        self.handle = h
+        self.devices = list(devices)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.zamd_multi_destroy(self.handle)
+            self.handle = None
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self.lib.zamd_multi_uses_rccl(self.handle))
+
+    def deflate(self, data, *, level: int = 6, strategy: int = 0, mem_level: int = 8, chunk_size: int = 1 << 20,
+                finish: bool = True, dictionary: bytes = b"", adler: int = 1, crc: int = 0):
+        """Host bytes in, (stream, chunk offsets + total, adler32, crc32) out."""
+        n = len(data)
+        nchunks = max(1, (n + chunk_size - 1) // chunk_size)
+        cap = self.lib.zamd_deflate_bound(n, chunk_size, mem_level) + 64
+        out = C.create_string_buffer(cap)
+        offs = (C.c_uint64 * (nchunks + 1))()
+        total, a, c = C.c_uint64(0), C.c_uint32(adler), C.c_uint32(crc)
+        src = C.create_string_buffer(bytes(data), max(n, 1))
+        _chk(self.lib.zamd_deflate_multi(self.handle, src, n, bytes(dictionary) if dictionary else None, len(dictionary), chunk_size,
+                                         level, strategy, mem_level, int(finish), out, cap, offs, C.byref(total), C.byref(a), C.byref(c)),
+             "zamd_deflate_multi")
+        return out.raw[:total.value], list(offs), a.value, c.value
 
 
 class Engine:

@@ -2563,6 +2563,25 @@ extern "C" int zamd_chunk_offsets_dev(zamd_engine *e, const uint64_t *d_lengths,
     return ZAMD_OK;
 }
 
+/* lengths[i] = offsets[i + 1] - offsets[i] for i < n, 0 for n <= i < pad_to */
+__global__ __launch_bounds__(256) void k_lengths(const uint64_t *off, uint64_t n, uint64_t pad_to, uint64_t *len)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < pad_to) len[i] = i < n ? off[i + 1] - off[i] : 0ull;
+}
+
+extern "C" int zamd_chunk_lengths_dev(zamd_engine *e, const uint64_t *d_offsets, uint64_t n, uint64_t *d_lengths, uint64_t pad_to)
+{
+    if (!e || !d_lengths || (!d_offsets && n)) return ZAMD_STREAM_ERROR;
+    if (pad_to < n) pad_to = n;
+    if (pad_to == 0) return ZAMD_OK;
+    HIPCHK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_lengths, dim3((uint32_t)((pad_to + 255) / 256)), dim3(256), 0, e->st[0], d_offsets, n, pad_to, d_lengths);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->st[0]));
+    return ZAMD_OK;
+}
+
 extern "C" int zamd_engine_on_launched(zamd_engine *e, void (*fn)(void *), void *arg)
 {
     if (!e) return ZAMD_STREAM_ERROR;

@@ -50,6 +50,29 @@ struct Gpu {
 };
 Gpu g_gpu;
 
+// ZAMD_DEVICES=0,1,...: deflate() calls that bring several batches at once spread them over these devices
+// (zamd_deflate_multi), one engine each besides the one above.  Caller holds g_gpu.mu.
+zamd_multi *g_multi = nullptr; bool g_multi_tried = false;
+zamd_multi *multi_locked() {
+    if (!g_multi_tried) {
+        g_multi_tried = true;
+        const char *v = getenv("ZAMD_DEVICES");
+        std::vector<int> devs;
+        for (const char *p = v; p && *p;) {
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p) break;
+            devs.push_back((int)d);
+            p = *end == ',' ? end + 1 : end;
+        }
+        if (devs.size() >= 2 && zamd_multi_create(&g_multi, devs.data(), (int)devs.size(), 0) != 0) {
+            fprintf(stderr, "zamd_z: ZAMD_DEVICES=%s: the devices could not be set up; one device is used\n", v);
+            g_multi = nullptr;
+        }
+    }
+    return g_multi;
+}
+
 // Caller holds g_gpu.mu.
 zamd_engine *engine_locked() {
     if (!g_gpu.tried) {
@@ -493,6 +516,39 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
     return err ? z_code(err) : Z_OK;
 }
 
+// `n` bytes of the caller's input straight to the caller's output on all the devices of ZAMD_DEVICES at once: contiguous
+// ranges of chunks, one per device (zamd_deflate_multi).  Returns NO_MULTI when the call is not one for that path.
+const int NO_MULTI = 200;
+int run_multi(z_streamp strm, DState *s, uint64_t n, int finish) {
+    if (s->prime_bits || s->w_bits != 15 || s->hist_len > HIST) return NO_MULTI;
+    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    zamd_multi *m = multi_locked();
+    if (!m) return NO_MULTI;
+    const int nd = zamd_multi_devices(m);
+    struct Reset { zamd_multi *m; int nd; ~Reset() { for (int i = 0; i < nd; i++) zamd_engine_tune(zamd_multi_engine(m, i), 0, 0, 0, 0); } } reset = {m, nd};
+    if (s->tuned) for (int i = 0; i < nd; i++) if (zamd_engine_tune(zamd_multi_engine(m, i), s->tune[0], s->tune[1], s->tune[2], s->tune[3]) != 0) return Z_STREAM_ERROR;
+    Trace tr;
+    const uint64_t nch = n ? (n + s->chunk_size - 1) / s->chunk_size : 1;
+    std::vector<uint64_t> off(s->index_on && s->index_ok ? nch + 1 : 0);
+    uint64_t total = 0;
+    uint32_t a = (uint32_t)strm->adler, c = (uint32_t)strm->adler;
+    int rc = zamd_deflate_multi(m, strm->next_in, n, s->hist.data(), s->hist_len, s->chunk_size, s->level, s->strategy, s->mem_level, finish,
+                                strm->next_out, strm->avail_out, off.empty() ? nullptr : off.data(), &total,
+                                s->wrap == 1 ? &a : nullptr, s->wrap == 2 ? &c : nullptr);
+    tr.lap("deflate on all devices"); tr.done("deflate, several devices");
+    if (rc != 0) return z_code(rc);
+    if (s->wrap == 1) strm->adler = a; else if (s->wrap == 2) strm->adler = c;
+    for (uint64_t k = 0; k + 1 < off.size(); k++) {
+        s->index.push_back((uint32_t)(off[k + 1] - off[k]));
+        s->index.push_back((uint32_t)(n ? ((k + 1) * s->chunk_size <= n ? s->chunk_size : n - k * s->chunk_size) : 0));
+    }
+    if (strm->data_type == Z_UNKNOWN) { int dt = zamd_engine_data_type(zamd_multi_engine(m, 0)); if (dt != Z_UNKNOWN) strm->data_type = dt; }
+    batch_history(s, strm->next_in, n);
+    strm->next_in += n; strm->avail_in -= (uInt)n; strm->total_in += n;
+    strm->next_out += total; strm->avail_out -= (uInt)total; strm->total_out += total;
+    return Z_OK;
+}
+
 void reset_history(DState *s) { s->hist.clear(); s->hist_len = 0; s->since_reset = 0; }
 
 // `compressed`: the engine call that ends the flush has run already (as the last of a row of overlapped batches)
@@ -762,7 +818,18 @@ static int deflate_body(z_streamp strm, int flush) {
             const uint64_t fit = (uint64_t)strm->avail_out / per;
             if (full + (with_last ? 1 : 0) > fit) { with_last = false; if (full > fit) full = fit; }
         }
-        if (full + (with_last ? 1 : 0) >= 2 && full >= 1 && s->out.size() == s->out_pos && s->batch_bytes >= 65536 && !getenv("ZAMD_Z_NO_PIPELINE")) {
+        // several devices: the whole row of batches as one call on all of them (flushes that end inside a byte stay on one)
+        static const bool multi_on = getenv("ZAMD_DEVICES") != nullptr;
+        const bool row = full + (with_last ? 1 : 0) >= 2 && full >= 1 && s->out.size() == s->out_pos;
+        rc = NO_MULTI;
+        if (multi_on && row && !(with_last && (flush == Z_PARTIAL_FLUSH || flush == Z_BLOCK))) {
+            const uint64_t n = with_last ? strm->avail_in : full * s->batch_bytes;
+            if (strm->avail_out >= zamd_deflate_bound(n, s->chunk_size, s->mem_level) + 64) rc = run_multi(strm, s, n, with_last && flush == Z_FINISH);
+            if (rc != NO_MULTI && rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
+            if (rc == Z_OK && with_last) { flushed = true; break; }
+        }
+        if (rc == Z_OK) { /* done on all devices */ }
+        else if (row && s->batch_bytes >= 65536 && !getenv("ZAMD_Z_NO_PIPELINE")) {
             rc = run_batches_piped(strm, s, full, with_last ? flush : Z_NO_FLUSH);
             if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
             if (with_last) { flushed = true; break; }
