@@ -227,7 +227,20 @@ int zamd_inflate_index_hint_splits(z_streamp strm, const unsigned long long *rec
 int zamd_z_last_error(void);
 /* The same index kept in a gzip file: gzopen(path, "wbI") (or ZAMD_GZ_INDEX=1) appends it as empty gzip members
  * that every gzip reader skips; gzopen for reading finds and uses it (ZAMD_GZ_INDEX=0: ignores it). */
-typedef struct zamd_gz_index { unsigned long long member_offset; unsigned n_chunks; unsigned *pairs; } zamd_gz_index;
+unsigned zamd_deflate_chunk_bytes(z_streamp strm);          /* the chunk size of this stream's grid (input bytes) */
+unsigned long long zamd_inflate_hinted_chunks(z_streamp strm);   /* chunks inflate() has placed by their index entries so far */
+/* Random access (the reference keeps such access points in memory while it inflates a file once, examples/zran.c:67-72,
+ * 249-349): a file written with a 'W' in the mode string (or ZAMD_GZ_WINDOWS=n in the environment: every n-th chunk) also
+ * stores, in front of the index, the 32 KiB of data in front of every n-th chunk, each in an empty gzip member of its
+ * own.  gzseek() on such a file reads the one window it needs and inflates from that chunk on; without windows it
+ * inflates from the start of the file, as the reference's does (gzlib.c:362-436).  The data's CRC-32 is not checked on a
+ * pass that began with such a seek.  Cost: 32 KiB per window, 3 % of the data at the default chunk size with n = 1. */
+typedef struct zamd_gz_index {
+    unsigned long long member_offset; unsigned n_chunks; unsigned *pairs;
+    unsigned long long window_offset; unsigned window_every, n_windows;      /* file offset of the first window member; 0, 0, 0: none */
+} zamd_gz_index;
+/* chunks placed by index entries since the file was opened, and seeks that started from a stored window */
+int zamd_gz_seek_stats(gzFile file, unsigned long long *chunks_decoded, unsigned long long *window_seeks);
 int zamd_gz_index_load(int fd, zamd_gz_index *out);          /* 0 = found, -1 = the file carries no index */
 void zamd_gz_index_free(zamd_gz_index *ix);
 

@@ -35,7 +35,8 @@ _lib = None
 
 
 class GzIndex(C.Structure):
-    _fields_ = [("member_offset", C.c_ulonglong), ("n_chunks", C.c_uint), ("pairs", C.POINTER(C.c_uint))]
+    _fields_ = [("member_offset", C.c_ulonglong), ("n_chunks", C.c_uint), ("pairs", C.POINTER(C.c_uint)),
+                ("window_offset", C.c_ulonglong), ("window_every", C.c_uint), ("n_windows", C.c_uint)]
 
 
 def lib():
@@ -114,6 +115,7 @@ def lib():
         l.zamd_inflate_index_hint_splits.argtypes = [P, C.POINTER(C.c_ulonglong), C.c_uint]
         l.zamd_gz_index_load.argtypes = [C.c_int, C.POINTER(GzIndex)]
         l.zamd_gz_index_free.argtypes = [C.POINTER(GzIndex)]; l.zamd_gz_index_free.restype = None
+        l.zamd_gz_seek_stats.argtypes = [G, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
         _lib = l
     return _lib
 

@@ -239,3 +239,73 @@ print("ok")
 ''' % ROOT
     r = subprocess.run([os.sys.executable, "-c", script, str(tmp_path / "f.gz")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
+def test_gzseek_starts_from_the_window_in_front_of_the_chunk(tmp_path):
+    """A file written with 'W' stores the 32 KiB in front of every chunk beside the index (what examples/zran.c:67-72 keeps
+    in memory): gzseek to any offset then inflates one chunk, not the file from its start.  256 MiB, 20 random offsets,
+    forwards and backwards; other gzip readers still read the file, and a reader that ignores the index reads the same."""
+    import random
+    import zlib_amd
+    l = Z.lib()
+    n = 256 << 20
+    data = bytes(zlib_amd.corpus(n, 4, 77, piece_bytes=16 << 20, threads=8))
+    name = str(tmp_path / "big.gz").encode()
+    g = l.gzopen(name, b"wb6W")
+    assert g
+    for at in range(0, n, 48 << 20):
+        piece = data[at:at + (48 << 20)]
+        assert l.gzwrite(g, piece, len(piece)) == len(piece)
+    assert l.gzclose(g) == Z.Z_OK
+    size = os.path.getsize(name)
+    fd = os.open(name, os.O_RDONLY)
+    ix = Z.GzIndex()
+    assert l.zamd_gz_index_load(fd, C.byref(ix)) == 0
+    assert ix.n_chunks == 256 and ix.window_every == 1 and ix.n_windows == 255 and 0 < ix.window_offset < size
+    l.zamd_gz_index_free(C.byref(ix))
+    os.close(fd)
+    assert size < 0.6 * n                                                  # windows cost 3 % of the data, not more
+
+    g = l.gzopen(name, b"rb")
+    assert g
+    rng = random.Random(5)
+    buf = C.create_string_buffer(70000)
+    chunks, seeks = C.c_ulonglong(0), C.c_ulonglong(0)
+    offsets = [rng.randrange(1 << 20, n - 70000) for _ in range(18)] + [n - 5000, (200 << 20) - 10]      # the last chunk; across a chunk boundary
+    for k, off in enumerate(offsets):
+        assert l.zamd_gz_seek_stats(g, C.byref(chunks), C.byref(seeks)) == 0
+        before, seeks_before = chunks.value, seeks.value
+        assert l.gzseek64(g, off, 0) == off
+        want = 5000 if off == n - 5000 else 30
+        assert l.gzread(g, buf, want) == want, l.gzerror(g, None)
+        assert buf.raw[:want] == data[off:off + want], (k, off)
+        assert l.gztell64(g) == off + want
+        assert l.zamd_gz_seek_stats(g, C.byref(chunks), C.byref(seeks)) == 0
+        assert seeks.value == seeks_before + 1, (k, off)
+        assert chunks.value - before <= 2, (k, off, chunks.value - before)
+    # reading on from where a seek ended, across chunks and to the end of the file
+    off = n - (3 << 20) - 777
+    assert l.gzseek64(g, off, 0) == off
+    assert _read_all(l, g, 1 << 20) == data[off:]
+    assert l.gzeof(g) == 1
+    # a short seek forwards inside what is already inflated stays the ordinary kind
+    assert l.gzseek64(g, 5 << 20, 0) == 5 << 20
+    assert l.gzread(g, buf, 10) == 10 and buf.raw[:10] == data[5 << 20:(5 << 20) + 10]
+    assert l.zamd_gz_seek_stats(g, C.byref(chunks), C.byref(seeks)) == 0
+    s0 = seeks.value
+    assert l.gzseek64(g, 100, 1) == (5 << 20) + 110
+    assert l.gzread(g, buf, 10) == 10 and buf.raw[:10] == data[(5 << 20) + 110:(5 << 20) + 120]
+    assert l.zamd_gz_seek_stats(g, C.byref(chunks), C.byref(seeks)) == 0 and seeks.value == s0
+    assert l.gzclose(g) == Z.Z_OK
+
+    # another reader (system zlib) and this one without the index
+    with gzip.open(name.decode()) as f:
+        assert f.read(1 << 20) == data[:1 << 20]
+        f.seek(100 << 20)
+        assert f.read(1000) == data[100 << 20:(100 << 20) + 1000]
+    env = dict(os.environ, ZAMD_GZ_INDEX="0")
+    code = ("import ctypes as C, sys\nsys.path.insert(0, %r)\nimport _zapi as Z\nl = Z.lib()\ng = l.gzopen(%r, b'rb')\n"
+            "buf = C.create_string_buffer(1000)\nassert l.gzseek64(g, 150 << 20, 0) == 150 << 20\nassert l.gzread(g, buf, 1000) == 1000\n"
+            "sys.stdout.buffer.write(buf.raw)\n" % (os.path.join(ROOT, "tests"), name))
+    r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0 and r.stdout == data[150 << 20:(150 << 20) + 1000], r.stderr[-500:]

@@ -56,8 +56,18 @@ struct GzFile {
     int want_index, members;    /* chunk index asked for; gzip members finished so far */
     uint64_t base, produced, member_at;   /* file offset at open, deflate() output so far, where the open member started */
     std::vector<unsigned> index; uint64_t index_member;
+    unsigned win_every, chunk_bytes;      /* windows wanted in front of every win_every-th chunk (0: none); the chunk grid */
+    uint64_t upos;                        /* input bytes of the open member handed to deflate() so far */
+    std::vector<unsigned char> wtail;     /* the last 32 KiB of them */
+    std::vector<std::vector<unsigned char> > windows;
     /* reading */
     std::vector<unsigned> ridx; uint64_t ridx_member; int have_ridx;
+    uint64_t ridx_woff; unsigned ridx_wevery, ridx_nwin;   /* where the window members start, their spacing and number */
+    uint64_t data_start;                  /* file offset of the indexed member's deflate data (0: not looked up yet) */
+    int raw_mode;                         /* inflating from a stored window: raw deflate, the member's trailer is skipped by hand */
+    unsigned skip_trailer; uint64_t read_limit;   /* trailer bytes still to skip; compressed bytes the next refills may load (0: no limit) */
+    uint64_t out_limit;                   /* and what they inflate to: the next fetch asks for no more (0: no limit) */
+    uint64_t window_seeks;
     /* seek request */
     z_off64_t skip; int seek;
     /* error */
@@ -80,7 +90,7 @@ void set_error(GzFile *s, int err, const char *msg)      /* gz_error, gzlib.c:57
 void reset(GzFile *s)                                    /* gz_reset, gzlib.c:75-88 */
 {
     s->x.have = 0;
-    if (s->mode == GZ_READ) { s->eof = 0; s->past = 0; s->how = LOOK; }
+    if (s->mode == GZ_READ) { s->eof = 0; s->past = 0; s->how = LOOK; s->skip_trailer = 0; s->read_limit = 0; s->out_limit = 0; }
     s->seek = 0;
     set_error(s, Z_OK, NULL);
     s->x.pos = 0;
@@ -107,7 +117,10 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
     s->mode = GZ_NONE; s->level = Z_DEFAULT_COMPRESSION; s->strategy = Z_DEFAULT_STRATEGY; s->direct = 0;
     s->err = Z_OK; s->how = LOOK; s->eof = s->past = 0; s->seek = 0; s->skip = 0; s->start = 0;
     s->want_index = 0; s->members = 0; s->base = s->produced = s->member_at = s->index_member = 0; s->have_ridx = 0; s->ridx_member = 0;
+    s->win_every = 0; s->chunk_bytes = 0; s->upos = 0;
+    s->ridx_woff = 0; s->ridx_wevery = s->ridx_nwin = 0; s->data_start = 0; s->raw_mode = 0; s->skip_trailer = 0; s->read_limit = 0; s->out_limit = 0; s->window_seeks = 0;
     { const char *v = getenv("ZAMD_GZ_INDEX"); if (v && *v && *v != '0') s->want_index = 1; }
+    { const char *v = getenv("ZAMD_GZ_WINDOWS"); if (v && atoi(v) > 0) { s->win_every = (unsigned)atoi(v); s->want_index = 1; } }
     int cloexec = 0, exclusive = 0;
     for (; *mode; mode++) {
         if (*mode >= '0' && *mode <= '9') { s->level = *mode - '0'; continue; }
@@ -124,6 +137,7 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
         case 'F': s->strategy = Z_FIXED; break;
         case 'T': s->direct = 1; break;
         case 'I': s->want_index = 1; break;            /* this library only: append a chunk index */
+        case 'W': s->want_index = 1; if (!s->win_every) s->win_every = 1; break;   /* and the window in front of every chunk */
         default: break;                                /* 'b' and anything unknown */
         }
     }
@@ -152,6 +166,7 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
             if (zamd_gz_index_load(s->fd, &ix) == 0) {
                 s->ridx.assign(ix.pairs, ix.pairs + 2 * (size_t)ix.n_chunks);
                 s->ridx_member = ix.member_offset; s->have_ridx = 1;
+                s->ridx_woff = ix.window_offset; s->ridx_wevery = ix.window_every; s->ridx_nwin = ix.n_windows;
                 zamd_gz_index_free(&ix);
             }
             lseek(s->fd, s->start, SEEK_SET);
@@ -190,8 +205,10 @@ int refill(GzFile *s)                                   /* gz_avail, gzread.c:51
     if (s->eof == 0) {
         z_stream &z = s->strm;
         if (z.avail_in) memmove(s->in.data(), z.next_in, z.avail_in);
-        unsigned got;
-        if (load(s, s->in.data() + z.avail_in, s->size - z.avail_in, &got) == -1) return -1;
+        unsigned got, want = s->size - z.avail_in;
+        if (s->read_limit && want > s->read_limit) want = (unsigned)s->read_limit;     /* after a seek: just the chunks asked for */
+        if (load(s, s->in.data() + z.avail_in, want, &got) == -1) return -1;
+        if (s->read_limit) s->read_limit -= got < s->read_limit ? got : s->read_limit;
         z.avail_in += got;
         z.next_in = s->in.data();
     }
@@ -212,12 +229,23 @@ int look(GzFile *s)                                     /* gz_look, gzread.c:86-
             return -1;
         }
     }
+    while (s->skip_trailer) {                           /* crc and length of a member that was inflated as raw deflate data */
+        if (z.avail_in == 0) { if (refill(s) == -1) return -1; if (z.avail_in == 0) break; }
+        const unsigned n = z.avail_in < s->skip_trailer ? z.avail_in : s->skip_trailer;
+        z.next_in += n; z.avail_in -= n; s->skip_trailer -= n;
+    }
     if (z.avail_in < 2) {
         if (refill(s) == -1) return -1;
         if (z.avail_in == 0) return 0;
     }
     if (z.avail_in > 1 && z.next_in[0] == 31 && z.next_in[1] == 139) {
-        inflateReset(&z);
+        if (s->have_ridx && s->ridx_nwin) {
+            /* the window members and the index behind them hold no data: reading ends where they start */
+            const z_off64_t at = lseek(s->fd, 0, SEEK_CUR);
+            if (at != -1 && (uint64_t)at - z.avail_in == s->ridx_woff) { z.avail_in = 0; s->eof = 1; s->x.have = 0; lseek(s->fd, 0, SEEK_END); return 0; }
+        }
+        if (s->raw_mode) { inflateReset2(&z, 15 + 16); s->raw_mode = 0; }
+        else inflateReset(&z);
         if (s->have_ridx) {
             z_off64_t at = lseek(s->fd, 0, SEEK_CUR);
             if (at != -1 && (uint64_t)at - z.avail_in == s->ridx_member)
@@ -254,7 +282,7 @@ int decomp(GzFile *s)                                   /* gz_decomp, gzread.c:1
     } while (z.avail_out && ret != Z_STREAM_END);
     s->x.have = had - z.avail_out;
     s->x.next = z.next_out - s->x.have;
-    if (ret == Z_STREAM_END) s->how = LOOK;             /* another member may follow */
+    if (ret == Z_STREAM_END) { s->how = LOOK; if (s->raw_mode) s->skip_trailer = 8; }   /* another member may follow */
     return 0;
 }
 
@@ -273,6 +301,7 @@ int fetch(GzFile *s)                                    /* gz_fetch, gzread.c:22
             return 0;
         case GZIP:
             z.avail_out = s->size << 1; z.next_out = s->out.data();
+            if (s->out_limit) { if (s->out_limit < z.avail_out) z.avail_out = (unsigned)s->out_limit; s->out_limit = 0; }
             if (decomp(s) == -1) return -1;
         }
     } while (s->x.have == 0 && (!s->eof || z.avail_in));
@@ -309,6 +338,7 @@ int winit(GzFile *s)                                    /* gz_init, gzwrite.c:15
             return -1;
         }
         if (s->want_index) zamd_deflate_index(&z, 1);
+        s->chunk_bytes = zamd_deflate_chunk_bytes(&z);
     }
     s->size = s->want;
     if (!s->direct) { z.avail_out = s->size; z.next_out = s->out.data(); s->x.next = z.next_out; }
@@ -325,10 +355,36 @@ int write_all(GzFile *s, const unsigned char *p, size_t n)
     return 0;
 }
 
+/* The input passes by once: what lies in front of every win_every-th chunk boundary is kept (the windows of the index). */
+void note_input(GzFile *s, const unsigned char *p, size_t n)
+{
+    const uint64_t step = (uint64_t)s->chunk_bytes * s->win_every;
+    if (step < 32768) return;
+    for (uint64_t b = (s->upos / step + 1) * step; b <= s->upos + n; b += step) {
+        const size_t from_p = (size_t)(b - s->upos);            /* bytes of p in front of the boundary */
+        std::vector<unsigned char> w(32768);
+        if (from_p >= 32768) memcpy(w.data(), p + from_p - 32768, 32768);
+        else {
+            const size_t need = 32768 - from_p;                 /* the rest is the end of what passed before */
+            memcpy(w.data(), s->wtail.data() + s->wtail.size() - need, need);
+            memcpy(w.data() + need, p, from_p);
+        }
+        s->windows.push_back(std::move(w));
+    }
+    if (n >= 32768) s->wtail.assign(p + n - 32768, p + n);
+    else {
+        s->wtail.insert(s->wtail.end(), p, p + n);
+        if (s->wtail.size() > 32768) s->wtail.erase(s->wtail.begin(), s->wtail.end() - 32768);
+    }
+    s->upos += n;
+}
+
 int comp(GzFile *s, int flush)                          /* gz_comp, gzwrite.c:74-131 */
 {
     z_stream &z = s->strm;
     if (s->size == 0 && winit(s) == -1) return -1;
+    /* at this point the bytes at next_in are new: a comp() that returns without an error has handed all of them over */
+    if (s->win_every && !s->direct && s->members == 0 && z.avail_in) note_input(s, z.next_in, z.avail_in);
     if (s->direct) {
         if (write_all(s, z.next_in, z.avail_in) == -1) return -1;
         z.avail_in = 0;
@@ -400,27 +456,122 @@ void put16(std::vector<unsigned char> &v, unsigned x) { v.push_back((unsigned ch
 void put32(std::vector<unsigned char> &v, uint32_t x) { put16(v, x & 0xffffu); put16(v, x >> 16); }
 void put64(std::vector<unsigned char> &v, uint64_t x) { put32(v, (uint32_t)x); put32(v, (uint32_t)(x >> 32)); }
 
+/* One window member: the same empty gzip member with the subfield 'Z' 'W': u8 version (1), u8 0, u16 0, u32 number of
+ * the chunk the window lies in front of, 32768 bytes.  All window members have the same size (WIN_MEMBER), so the j-th
+ * one is found without reading the others; they stand between the data and the index members, and the last index member
+ * says where they start: with flags bit 1 set its payload holds, in front of the closing 12 bytes,
+ * u64 offset in the file of the first window member, u32 spacing in chunks, u32 number of windows. */
+const unsigned WIN_MEMBER = 10 + 2 + 4 + 8 + 32768 + 10;
 int write_index(GzFile *s)
 {
     const size_t nch = s->index.size() / 2;
-    const uint64_t first_member = s->base + s->produced;
     std::vector<unsigned char> o;
+    static const unsigned char head[10] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 3};
+    /* windows in front of chunks that exist */
+    size_t nwin = 0;
+    if (s->win_every && nch > 1) { nwin = (nch - 1) / s->win_every; if (nwin > s->windows.size()) nwin = s->windows.size(); }
+    const uint64_t first_window = s->base + s->produced;
+    for (size_t j = 0; j < nwin; j++) {
+        o.insert(o.end(), head, head + 10);
+        put16(o, 4u + 8u + 32768u);
+        o.push_back('Z'); o.push_back('W'); put16(o, 8u + 32768u);
+        o.push_back(1); o.push_back(0); put16(o, 0); put32(o, (uint32_t)((j + 1) * s->win_every));
+        o.insert(o.end(), s->windows[j].begin(), s->windows[j].end());
+        o.push_back(3); o.push_back(0);
+        for (int k = 0; k < 8; k++) o.push_back(0);
+        if (o.size() >= (8u << 20)) { if (write_all(s, o.data(), o.size()) == -1) return -1; o.clear(); }
+    }
+    const uint64_t first_member = first_window + (uint64_t)nwin * WIN_MEMBER;
     for (size_t c0 = 0; c0 < nch; c0 += IDX_PER_MEMBER) {
         const size_t n = nch - c0 < IDX_PER_MEMBER ? nch - c0 : IDX_PER_MEMBER;
         const bool last = c0 + n == nch;
-        const unsigned payload = 24u + 8u * (unsigned)n + (last ? 12u : 0u);
-        static const unsigned char head[10] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 3};
+        const bool wins = last && nwin != 0;
+        const unsigned payload = 24u + 8u * (unsigned)n + (wins ? 16u : 0u) + (last ? 12u : 0u);
         o.insert(o.end(), head, head + 10);
         put16(o, payload + 4u);
         o.push_back('Z'); o.push_back('I'); put16(o, payload);
-        o.push_back(1); o.push_back(last ? 1 : 0); put16(o, 0); put32(o, (uint32_t)n);
+        o.push_back(1); o.push_back((last ? 1 : 0) | (wins ? 2 : 0)); put16(o, 0); put32(o, (uint32_t)n);
         put64(o, s->index_member); put64(o, c0);
         for (size_t c = c0; c < c0 + n; c++) { put32(o, s->index[2 * c]); put32(o, s->index[2 * c + 1]); }
+        if (wins) { put64(o, first_window); put32(o, s->win_every); put32(o, (uint32_t)nwin); }
         if (last) { put64(o, first_member); o.push_back('Z'); o.push_back('A'); o.push_back('M'); o.push_back('I'); }
         o.push_back(3); o.push_back(0);
         for (int k = 0; k < 8; k++) o.push_back(0);
     }
     return write_all(s, o.data(), o.size());
+}
+
+/* Where the deflate data of the gzip member at `member` starts: behind the fixed header and whatever optional fields its
+ * flags announce (RFC 1952; deflate.c:690-867 writes them, inflate.c:653-799 reads them).  0: not a gzip header. */
+uint64_t gzip_data_start(int fd, uint64_t member)
+{
+    unsigned char h[12];
+    if (pread(fd, h, 12, (off_t)member) < 10 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8) return 0;
+    uint64_t at = member + 10;
+    const unsigned flg = h[3];
+    if (flg & 4) { at += 2u + ((unsigned)h[10] | ((unsigned)h[11] << 8)); }
+    for (int field = 0; field < 2; field++) {            /* name, comment: up to a zero byte each */
+        if (!(flg & (field == 0 ? 8 : 16))) continue;
+        for (;;) {
+            unsigned char b[4096];
+            const ssize_t r = pread(fd, b, sizeof b, (off_t)at);
+            if (r <= 0) return 0;
+            const void *z0 = memchr(b, 0, (size_t)r);
+            if (z0) { at += (uint64_t)((const unsigned char *)z0 - b) + 1; break; }
+            at += (uint64_t)r;
+        }
+    }
+    if (flg & 2) at += 2;
+    return at;
+}
+
+/* gzseek() to `target` (an offset in the inflated data) through the stored windows: 1 = the file is positioned at the
+ * chunk boundary in front of the target with inflate() set up to start there, 0 = not possible or not worth it (the
+ * caller goes on the ordinary way), -1 = error. */
+int window_seek(GzFile *s, z_off64_t target)
+{
+    if (!s->have_ridx || !s->ridx_nwin || !s->ridx_wevery || s->ridx.size() < 4) return 0;
+    const size_t nch = s->ridx.size() / 2;
+    const uint64_t chunk0 = s->ridx[1];
+    if (chunk0 < 32768) return 0;
+    uint64_t total = 0;
+    for (size_t c = 0; c < nch; c++) { if (c + 1 < nch && s->ridx[2 * c + 1] != chunk0) return 0; total += s->ridx[2 * c + 1]; }
+    if ((uint64_t)target >= total) return 0;
+    const size_t c = (size_t)((uint64_t)target / chunk0);
+    const size_t a = c / s->ridx_wevery * s->ridx_wevery;          /* the chunk with a window in front of it, at or before c */
+    if (a == 0 || a / s->ridx_wevery - 1 >= s->ridx_nwin) return 0;
+    /* not worth it when the data in between is about to be inflated anyway */
+    if (target >= s->x.pos && (uint64_t)a * chunk0 <= (uint64_t)s->x.pos + s->x.have) return 0;
+    if (s->size == 0 && look(s) == -1) return -1;                  /* buffers and the inflate state */
+    unsigned char wh[24];
+    std::vector<unsigned char> win(32768);
+    const uint64_t wat = s->ridx_woff + (uint64_t)(a / s->ridx_wevery - 1) * WIN_MEMBER;
+    if (pread(s->fd, wh, 24, (off_t)wat) != 24 || wh[0] != 0x1f || wh[1] != 0x8b || wh[12] != 'Z' || wh[13] != 'W' || wh[16] != 1) return 0;
+    if (((uint32_t)wh[20] | ((uint32_t)wh[21] << 8) | ((uint32_t)wh[22] << 16) | ((uint32_t)wh[23] << 24)) != (uint32_t)a) return 0;
+    if (pread(s->fd, win.data(), 32768, (off_t)(wat + 24)) != 32768) return 0;
+    if (s->data_start == 0) s->data_start = gzip_data_start(s->fd, s->ridx_member);
+    if (s->data_start == 0) return 0;
+    uint64_t comp_at = s->data_start, need = 0;
+    for (size_t k = 0; k < a; k++) comp_at += s->ridx[2 * k];
+    const size_t upto = c + 1 < nch ? c + 1 : c;                   /* and the chunk behind it: a short read may run on into it */
+    for (size_t k = a; k <= upto; k++) need += s->ridx[2 * k];
+    if (lseek(s->fd, (off_t)comp_at, SEEK_SET) == -1) return -1;
+    z_stream &z = s->strm;
+    if (inflateReset2(&z, -15) != Z_OK || inflateSetDictionary(&z, win.data(), 32768) != Z_OK ||
+        zamd_inflate_index_hint(&z, s->ridx.data() + 2 * a, (unsigned)(nch - a)) != Z_OK) {
+        set_error(s, Z_STREAM_ERROR, "internal error: inflate stream corrupt");
+        return -1;
+    }
+    z.avail_in = 0; z.next_in = s->in.data();
+    s->x.have = 0; s->eof = 0; s->past = 0; s->seek = 0; s->skip_trailer = 0;
+    set_error(s, Z_OK, NULL);
+    s->how = GZIP; s->direct = 0; s->raw_mode = 1;
+    s->read_limit = need;                                          /* the first read brings just the chunks up to the target's */
+    s->out_limit = 0;
+    for (size_t k = a; k <= upto; k++) s->out_limit += s->ridx[2 * k + 1];
+    s->x.pos = (z_off64_t)((uint64_t)a * chunk0);
+    s->window_seeks++;
+    return 1;
 }
 
 }  // namespace
@@ -452,11 +603,19 @@ int zamd_gz_index_load(int fd, zamd_gz_index *out)
         const unsigned xlen = (unsigned)rd(h + 10, 2), plen = (unsigned)rd(h + 14, 2);
         const unsigned flags = h[17];
         const uint64_t n = rd(h + 20, 4), first = rd(h + 32, 8);
-        if (plen + 4u != xlen || plen != 24u + 8u * n + ((flags & 1) ? 12u : 0u) || first != pairs.size() / 2) return -1;
+        const unsigned ext = (flags & 2) ? 16u : 0u;
+        if (plen + 4u != xlen || plen != 24u + 8u * n + ext + ((flags & 1) ? 12u : 0u) || first != pairs.size() / 2) return -1;
+        if ((flags & 2) && !(flags & 1)) return -1;
         if (pairs.empty()) member = rd(h + 24, 8); else if (member != rd(h + 24, 8)) return -1;
-        std::vector<unsigned char> body(8 * n);
-        if (n && pread(fd, body.data(), body.size(), (off_t)(at + sizeof h)) != (ssize_t)body.size()) return -1;
+        std::vector<unsigned char> body(8 * n + ext);
+        if (!body.empty() && pread(fd, body.data(), body.size(), (off_t)(at + sizeof h)) != (ssize_t)body.size()) return -1;
         for (uint64_t i = 0; i < 2 * n; i++) pairs.push_back((unsigned)rd(body.data() + 4 * i, 4));
+        if (ext) {
+            out->window_offset = rd(body.data() + 8 * n, 8);
+            out->window_every = (unsigned)rd(body.data() + 8 * n + 8, 4);
+            out->n_windows = (unsigned)rd(body.data() + 8 * n + 12, 4);
+            if (out->window_every == 0 || out->window_offset + (uint64_t)out->n_windows * WIN_MEMBER > (uint64_t)end) { out->window_offset = 0; out->window_every = out->n_windows = 0; }
+        }
         at += 12 + xlen + 10;
         if (flags & 1) break;
     }
@@ -470,6 +629,15 @@ int zamd_gz_index_load(int fd, zamd_gz_index *out)
 }
 
 void zamd_gz_index_free(zamd_gz_index *ix) { if (ix) { free(ix->pairs); ix->pairs = NULL; ix->n_chunks = 0; } }
+
+int zamd_gz_seek_stats(gzFile file, unsigned long long *chunks_decoded, unsigned long long *window_seeks)
+{
+    GzFile *s = gz(file);
+    if (s == NULL || s->mode != GZ_READ) return -1;
+    if (chunks_decoded) *chunks_decoded = s->size ? zamd_inflate_hinted_chunks(&s->strm) : 0ull;
+    if (window_seeks) *window_seeks = s->window_seeks;
+    return 0;
+}
 
 gzFile gzopen(const char *path, const char *mode) { return open_file(path, -1, mode); }       /* gzlib.c:268 */
 gzFile gzopen64(const char *path, const char *mode) { return open_file(path, -1, mode); }     /* gzlib.c:276 */
@@ -517,6 +685,17 @@ static z_off64_t gzseek64_body(gzFile file, z_off64_t offset, int whence)       
         s->strm.avail_in = 0;
         s->x.pos += offset;
         return s->x.pos;
+    }
+    if (s->mode == GZ_READ && s->x.pos + offset >= 0 && s->ridx_nwin) {
+        /* a file that carries windows: start from the one in front of the target's chunk */
+        const z_off64_t target = s->x.pos + offset;
+        const int r = window_seek(s, target);
+        if (r == -1) return -1;
+        if (r == 1) {
+            const z_off64_t rest = target - s->x.pos;
+            if (rest) { s->seek = 1; s->skip = rest; }
+            return target;
+        }
     }
     if (offset < 0) {                                   /* backwards: only by reading again from the start */
         if (s->mode != GZ_READ) return -1;

@@ -911,6 +911,7 @@ int zamd_deflate_index_splits(z_streamp strm, const unsigned long long **recs, u
     *recs = (const unsigned long long *)s->splits.data(); *per_chunk = IDX_PARTS - 1;
     return Z_OK;
 }
+unsigned zamd_deflate_chunk_bytes(z_streamp strm) { DState *s = dstate(strm); return s ? s->chunk_size : 0u; }
 int zamd_deflate_index_get(z_streamp strm, const unsigned **pairs, unsigned *n_chunks) {
     DState *s = dstate(strm);
     if (!s || pairs == Z_NULL || n_chunks == Z_NULL) return Z_STREAM_ERROR;
@@ -949,9 +950,10 @@ struct IState {
     uint64_t prime_hold; unsigned prime_bits;   // inflatePrime bits waiting in front of the first input byte
     Words hints; size_t hint_pos;   // chunk index of the deflate data ahead (zamd_inflate_index_hint): compressed bytes, inflated bytes per chunk
     Longs hint_splits; unsigned hint_per;   // and hint_per split records per chunk (zamd_inflate_index_hint_splits), or none
+    uint64_t hinted_chunks;         // chunks placed by their index entries since inflateInit (zamd_inflate_hinted_chunks)
     size_t call_taken;              // bytes the current inflate() call has moved from next_in to the end of `in`
     explicit IState(z_streamp strm) : hdr(ZAlloc<uint8_t>(strm)), in(ZAlloc<uint8_t>(strm)), cands(ZAlloc<uint64_t>(strm)), out(ZAlloc<uint8_t>(strm)),
-                                      hist(ZAlloc<uint8_t>(strm)), hints(ZAlloc<uint32_t>(strm)), hint_splits(ZAlloc<uint64_t>(strm)), hint_per(0) {}
+                                      hist(ZAlloc<uint8_t>(strm)), hints(ZAlloc<uint32_t>(strm)), hint_splits(ZAlloc<uint64_t>(strm)), hint_per(0), hinted_chunks(0) {}
 };
 
 // Hands the bytes at the end of `in` that the current call took (at most `want` of them) back to the caller.
@@ -1454,7 +1456,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         produced = chain.back().out_off + chain.back().out_cap;
         end_bit = hinted ? chain.back().in_end_bit : chain.back().end_bit;
         if (good == chain.size() && chain.back().status == 1) final_block = true;
-        if (hinted) s->hint_pos += hints_used;
+        if (hinted) { s->hint_pos += hints_used; s->hinted_chunks += hints_used / 2; }
         if (s->wrap) strm->adler = s->check;
         const uint8_t *got = strm->next_out;
         strm->next_out += produced; strm->avail_out -= (uInt)produced; strm->total_out += produced;
@@ -1482,7 +1484,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
             for (size_t i = 0; i + 1 < chain.size(); i++)
                 if (chain[i].status == 1) { drop_hints(s); return HINT_MISFIT; }
             final_block = chain.back().status == 1;
-            s->hint_pos += hints_used;
+            { s->hint_pos += hints_used; s->hinted_chunks += hints_used / 2; }
         }
         tr.lap("place");
         if (s->wrap) {
@@ -1745,6 +1747,8 @@ static int zamd_inflate_index_hint_splits_body(z_streamp strm, const unsigned lo
     return Z_OK;
 }
 int zamd_inflate_index_hint_splits(z_streamp strm, const unsigned long long *recs, unsigned per_chunk) { return guarded(strm, [&] { return zamd_inflate_index_hint_splits_body(strm, recs, per_chunk); }); }
+
+unsigned long long zamd_inflate_hinted_chunks(z_streamp strm) { IState *s = istate(strm); return s ? s->hinted_chunks : 0ull; }
 
 int inflateGetDictionary(z_streamp strm, Bytef *dictionary, uInt *dictLength) {
     IState *s = istate(strm);
