@@ -36,9 +36,12 @@ const char *const k_errmsg[10] = {   // zutil.c:17-27
     "data error", "insufficient memory", "buffer error", "incompatible version", ""};
 inline const char *err_msg(int err) { return k_errmsg[Z_NEED_DICT - err]; }
 
-// ------------------------------------------------------------------ engine singleton
+// ------------------------------------------------------------------ engines
+// A lane is an engine with its staging buffers; a call that needs the GPU takes a free lane for as long as it runs, so
+// streams used from different threads at once (zlib.h:143-145) run side by side on the GPU up to the number of lanes
+// (ZAMD_Z_LANES, 1..8, default 4), and queue for a lane beyond that.  A program with one thread only ever sees lane 0.
 struct Gpu {
-    std::mutex mu;           // serialises every GPU call made through this API
+    std::mutex mu;           // held by the call that is using the lane
     zamd_engine *eng = nullptr;
     int rc = Z_OK;
     bool tried = false;
@@ -48,10 +51,33 @@ struct Gpu {
     uint8_t *d_out_b = nullptr; uint64_t out_cap_b = 0;
     uint64_t *d_off = nullptr; uint64_t off_cap = 0;
 };
-Gpu g_gpu;
+const int MAX_LANES = 8;
+Gpu g_lanes[MAX_LANES];
+thread_local Gpu *t_lane = nullptr;      // the lane this thread holds (helper threads of a call are given their call's lane)
+#define g_gpu (*t_lane)
+int lane_count() {
+    static const int n = [] { const char *v = getenv("ZAMD_Z_LANES"); int k = v ? atoi(v) : 4; return k < 1 ? 1 : k > MAX_LANES ? MAX_LANES : k; }();
+    return n;
+}
+struct LaneLock {
+    Gpu *prev;
+    LaneLock() : prev(t_lane) {
+        const int n = lane_count();
+        for (int i = 0; i < n; i++) if (g_lanes[i].mu.try_lock()) { t_lane = &g_lanes[i]; return; }
+        // all busy: wait for one; which one is spread over the threads so that they do not all queue at lane 0
+        static std::atomic<unsigned> turn{0};
+        Gpu *g = &g_lanes[turn.fetch_add(1) % (unsigned)n];
+        g->mu.lock();
+        t_lane = g;
+    }
+    ~LaneLock() { t_lane->mu.unlock(); t_lane = prev; }
+    LaneLock(const LaneLock &) = delete;
+    LaneLock &operator=(const LaneLock &) = delete;
+};
 
 // ZAMD_DEVICES=0,1,...: deflate() calls that bring several batches at once spread them over these devices
-// (zamd_deflate_multi), one engine each besides the one above.  Caller holds g_gpu.mu.
+// (zamd_deflate_multi), one engine each besides the lanes' own.  Caller holds g_multi_mu.
+std::mutex g_multi_mu;
 zamd_multi *g_multi = nullptr; bool g_multi_tried = false;
 zamd_multi *multi_locked() {
     if (!g_multi_tried) {
@@ -73,7 +99,7 @@ zamd_multi *multi_locked() {
     return g_multi;
 }
 
-// Caller holds g_gpu.mu.
+// Caller holds a lane (LaneLock).
 zamd_engine *engine_locked() {
     if (!g_gpu.tried) {
         g_gpu.tried = true;
@@ -383,7 +409,7 @@ inline int z_code(int rc) { return rc == 0 ? Z_OK : rc == ZAMD_MEM_ERROR ? Z_MEM
 // append the result to s->out and fold the bytes into strm->adler.
 // `tail`: how the output ends when finish == 0 (ZAMD_TAIL_*: sync marker, _tr_align, nothing).
 int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int finish, int tail = ZAMD_TAIL_SYNC) {
-    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    LaneLock lk;
     zamd_engine *e = engine_locked();
     if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
     Batch b;
@@ -417,7 +443,7 @@ int run_batch(z_streamp strm, DState *s, const uint8_t *src, uint64_t n, int fin
 // `last_flush` other than Z_NO_FLUSH: the rest of the input (shorter than a batch, possibly empty) follows as the
 // last batch of the row and ends the way finish_batch would end it.
 int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) {
-    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    LaneLock lk;
     zamd_engine *e = engine_locked();
     if (!e) return g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR;
     const uint64_t nb = s->batch_bytes;
@@ -448,7 +474,9 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
     uint64_t out_total = 0;
     Trace tr;
     std::vector<double> up_ms(count, 0.0), down_ms(count, 0.0);     // for the trace: how long each transfer took beside the kernels
+    Gpu *const lane = t_lane;
     std::thread up([&] {
+        t_lane = lane;
         for (uint64_t i = 0; i < count; i++) {
             { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || (computed + 2 > i && launched + 1 > i); }); if (err) return; }   // batch i - 2 is done with the slot, batch i - 1 is on the GPU
             const auto t0 = std::chrono::steady_clock::now();
@@ -470,6 +498,7 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
         }
     } up_guard = {up, mu, cv, err, e, streams_before, serialized_before, true};
     std::thread down([&] {
+        t_lane = lane;
         uint64_t at = 0;
         for (uint64_t i = 0; i < count; i++) {
             { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || (computed > i && (launched > i + 1 || i + 1 >= count)); }); if (computed <= i) return; }
@@ -521,7 +550,7 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
 const int NO_MULTI = 200;
 int run_multi(z_streamp strm, DState *s, uint64_t n, int finish) {
     if (s->prime_bits || s->w_bits != 15 || s->hist_len > HIST) return NO_MULTI;
-    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    std::lock_guard<std::mutex> lk(g_multi_mu);
     zamd_multi *m = multi_locked();
     if (!m) return NO_MULTI;
     const int nd = zamd_multi_devices(m);
@@ -1119,8 +1148,10 @@ int place_piped(zamd_engine *e, IState *s, const uint8_t *ip, size_t in_n, const
             if (b.joinable()) b.join();
         }
     } joiner = {up, down, mu, cv, err, computed, ng};
+    Gpu *const lane = t_lane;
     if (!d_comp)
         up = std::thread([&] {
+            t_lane = lane;
             for (size_t k = 0; k < ng; k++) {
                 { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || computed + 2 > k; }); if (err) return; }
                 int rc = zamd_dev_upload_staged(e, slot_in((int)(k & 1)), ip + gs[k].in0, gs[k].in_len);
@@ -1131,6 +1162,7 @@ int place_piped(zamd_engine *e, IState *s, const uint8_t *ip, size_t in_n, const
             }
         });
     down = std::thread([&] {
+        t_lane = lane;
         for (size_t k = 0; k < ng; k++) {
             { std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return err || computed > k; }); if (computed <= k) return; }
             t_down0[k] = now_ms();
@@ -1207,7 +1239,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     size_t &scanned = view ? view_scanned : s->scanned;
     if (in_n * 8ull <= s->bit_off) return view ? NO_PROGRESS : Z_OK;
     Trace tr;
-    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    LaneLock lk;
     zamd_engine *e = engine_locked();
     if (!e) return Z_MEM_ERROR;
     // the input goes to the device when somebody needs it there: a round that places chunks by their index in
@@ -1909,7 +1941,7 @@ static uLong checksum_failed(int crc, uLong start, int code, const char *what) {
 static uLong checksum_host_buf(int crc, uLong start, const Bytef *buf, uInt len) {
     if (buf == Z_NULL) return crc ? 0UL : 1UL;
     if (len == 0) return start;
-    std::lock_guard<std::mutex> lk(g_gpu.mu);
+    LaneLock lk;
     zamd_engine *e = engine_locked();
     if (!e) return checksum_failed(crc, start, g_gpu.rc ? g_gpu.rc : Z_STREAM_ERROR, "no GPU engine");
     if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, (uint64_t)len + 64) != Z_OK) return checksum_failed(crc, start, Z_MEM_ERROR, "device memory");
