@@ -1348,8 +1348,12 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         {
             static const uint64_t STEP = (getenv("ZAMD_Z_BLOCKSCAN_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_KIB"), nullptr, 10) : 32) * 8192ull;
             if (STEP && end_bits > s->bit_off + 2 * STEP) {
-                // only where sync markers are further apart than GAP: a stream cut into chunks has starts enough
-                static const uint64_t GAP = (getenv("ZAMD_Z_BLOCKSCAN_GAP_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_GAP_KIB"), nullptr, 10) : 2048) * 8192ull;
+                // only where sync markers are further apart than GAP.  A wavefront inflates about 20 MB a second: a round of
+                // few segments takes as long as its longest one, so a small round is cut finer than its sync markers cut it
+                // (a 1 MiB chunk alone takes 50 ms, eight pieces of it 7); a large round has segments enough to fill the GPU,
+                // and the search for block starts would cost more than the finer cut saves (87 ms on 1.7 GB of input)
+                static const uint64_t gap_env = getenv("ZAMD_Z_BLOCKSCAN_GAP_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_GAP_KIB"), nullptr, 10) : 0;
+                const uint64_t GAP = (gap_env ? gap_env : in_n <= (512ull << 20) ? 256 : 2048) * 8192ull;
                 std::vector<uint64_t> tg;
                 size_t ci = 0;                                   // first marker behind t
                 for (uint64_t t = s->bit_off + STEP; t + STEP / 2 <= end_bits && tg.size() < (1u << 16); t += STEP) {
