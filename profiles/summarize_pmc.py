@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc counter_collection CSVs per kernel.
 
-usage: summarize_pmc.py INPUT_BYTES FETCH_DIR WRITE_DIR > hbm_traffic.json
+usage: summarize_pmc.py INPUT_BYTES FETCH_DIR WRITE_DIR [--commit HASH] [--workload NAME] > hbm_traffic.json
 FETCH_DIR / WRITE_DIR hold the output of two separate passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE).
 FETCH_SIZE and WRITE_SIZE are reported in KB; on gfx950 FETCH_SIZE counts half the bytes of wide
 coalesced reads, hence the factor 2 on the read side.
@@ -45,7 +45,9 @@ def main():
         return all_counters(sys.argv[2:])
     n = int(sys.argv[1])
     rd, wr = collect(sys.argv[2], "FETCH_SIZE"), collect(sys.argv[3], "WRITE_SIZE")
-    out = {"input_bytes": n,
+    extra = sys.argv[4:]
+    opt = {extra[i].lstrip("-"): extra[i + 1] for i in range(0, len(extra) - 1, 2)}
+    out = {"input_bytes": n, "commit": opt.get("commit", "unknown"), "workload": opt.get("workload", "l6_mixed"),
            "note": "FETCH_SIZE / WRITE_SIZE in KB from two separate --pmc passes; hbm_read_bytes = 2 * FETCH_SIZE * 1024 (gfx950)",
            "kernels": {}}
     for k in sorted(set(rd) | set(wr)):
