@@ -207,9 +207,14 @@ def main():
     cap = lib.zamd_deflate_bound(n, CHUNK, mem)
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
     d_off = torch.empty(nchunks + 1, dtype=torch.int64, device="cuda")
+    # the deflate call also records block boundaries inside every chunk (8 bytes each, SPLIT_PARTS - 1 per chunk): the
+    # inflate leg puts several wavefronts on a chunk where the chunks alone do not fill the GPU (the library decides)
+    SPLIT_PARTS = 8
+    d_splits = torch.zeros(nchunks * (SPLIT_PARTS - 1), dtype=torch.int64, device="cuda")
     finish = rank == world - 1
 
     def step():
+        eng.record_splits(d_splits.data_ptr(), SPLIT_PARTS)
         total = eng.deflate_shard_dev(d_in, n, head, d_out.data_ptr(), cap, level=level, strategy=strategy, mem_level=mem,
                                       chunk_size=CHUNK, finish=finish, d_chunk_off=d_off.data_ptr())
         lens = d_off[1:] - d_off[:-1]
@@ -255,8 +260,10 @@ def main():
     names = {"chain": 0, "match": 1, "parse": 2, "plan": 3, "layout": 4, "emit": 5, "call": 6, "reach": 10, "first3": 11}
     kt = {nm: eng.timing_ms(i) for nm, i in names.items()}
     dominant = "match" if kt["match"][1] else "parse"     # levels 1-3 have no separate match kernel
+    if not kt["match"][1] and kt["plan"][0] > kt["parse"][0]:
+        dominant = "plan"                                   # Z_HUFFMAN_ONLY: no search and no parse to speak of
     # chain budgets from 256 on (levels 7-9) search along the four-byte chains: k_reach and k_first3 ran, the matcher is k_match4
-    kernel_name = ("k_match4" if kt["reach"][1] else "k_match") if dominant == "match" else \
+    kernel_name = ("k_match4" if kt["reach"][1] else "k_match") if dominant == "match" else "k_plan" if dominant == "plan" else \
                   ("k_fastw" if level == 1 else "k_fastr" if level in (2, 3) else "k_parse")
     roofline = None
     kt_serial = None
@@ -305,7 +312,8 @@ def main():
 
         def inf_step():
             if world == 1:
-                eng.inflate_dev(d_out.data_ptr(), d_off.data_ptr(), nchunks, d_back.data_ptr(), n, chunk_size=CHUNK, comp_bytes=int(total))
+                eng.inflate_dev(d_out.data_ptr(), d_off.data_ptr(), nchunks, d_back.data_ptr(), n, chunk_size=CHUNK, comp_bytes=int(total),
+                                d_splits=d_splits.data_ptr(), parts=SPLIT_PARTS)
             elif wdev == "cuda":
                 inflate_shard_handover(eng, rank, world, win_in, win_out, d_out.data_ptr(), int(total), d_off.data_ptr(), nchunks,
                                        d_back.data_ptr(), n, chunk_size=CHUNK)

@@ -38,6 +38,9 @@
 #ifndef ZI_STAGE
 #define ZI_STAGE  512u       /* elements of the per-wave output stage (>= 258) */
 #endif
+#ifndef ZI_SPLIT_SEGMENTS
+#define ZI_SPLIT_SEGMENTS 14336u   /* zamd_inflate_split_dev cuts chunks into parts while that many segments are not exceeded */
+#endif
 #define ZI_EMPTY  0xffffu    /* stage element not produced yet (no byte or marker has this value) */
 __constant__ uint8_t zi_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   /* inflate.c:608-609 */
 
@@ -920,14 +923,16 @@ extern "C" int zamd_inflate_shard_dev(zamd_engine *e, const void *d_comp, uint64
  * empty at the chunk's end.  A split record is (bit offset from the chunk's first byte) << 32 | offset of the
  * block's first byte in the chunk's output; records must ascend in both halves and stay inside the chunk, and the
  * first one that does not ends the chunk's list (the rest of the chunk is then one part). */
+/* `use` (<= parts): how many parts a chunk is cut into at most; of the chunk's parts - 1 records those nearest to the
+ * multiples of 1 / use are taken. */
 __global__ void k_inf_setup_parts(const uint64_t *chunk_off, uint64_t nchunks, uint32_t chunk_size, uint64_t n_out, uint64_t out_base,
-                                  uint32_t head_avail, const uint64_t *splits, uint32_t parts, ZiSeg *segs)
+                                  uint32_t head_avail, const uint64_t *splits, uint32_t parts, uint32_t use, ZiSeg *segs)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nchunks) return;
     const uint64_t bit0 = chunk_off[i] * 8ull, bit1 = chunk_off[i + 1] * 8ull, o0 = i * (uint64_t)chunk_size;
     const uint64_t rest = n_out > o0 ? n_out - o0 : 0, clen = rest < chunk_size ? rest : chunk_size;
-    ZiSeg *out = segs + i * parts;
+    ZiSeg *out = segs + i * use;
     uint32_t idx = 0;
     uint64_t pbit = bit0, pout = 0;
     auto put = [&](uint64_t b0, uint64_t b1, uint64_t off, uint64_t cap) {
@@ -939,7 +944,8 @@ __global__ void k_inf_setup_parts(const uint64_t *chunk_off, uint64_t nchunks, u
         s.out_len = 0; s.end_bit = 0; s.status = 0xffffffffu; s.final_seen = 0; s.stop_bit = 0;
         out[idx++] = s;
     };
-    for (uint32_t k = 0; k + 1 < parts; k++) {
+    for (uint32_t j = 1; j < use; j++) {
+        const uint32_t k = j * parts / use - 1u;
         const uint64_t rec = splits[i * (parts - 1u) + k];
         const uint64_t bit = bit0 + (rec >> 32), off = rec & 0xffffffffull;
         if (rec == 0 || off <= pout || off >= clen || bit <= pbit || bit >= bit1) break;
@@ -947,7 +953,7 @@ __global__ void k_inf_setup_parts(const uint64_t *chunk_off, uint64_t nchunks, u
         pbit = bit; pout = off;
     }
     put(pbit, bit1, pout, clen - pout);
-    while (idx < parts) put(bit1, bit1, clen, 0);
+    while (idx < use) put(bit1, bit1, clen, 0);
 }
 
 extern "C" int zamd_inflate_split_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, const uint64_t *d_chunk_off, uint64_t n_chunks,
@@ -961,11 +967,17 @@ extern "C" int zamd_inflate_split_dev(zamd_engine *e, const void *d_comp, uint64
     if (n_chunks == 0 || n_chunks > 0x7fffffffull / 32 / parts) return ZAMD_STREAM_ERROR;
     if ((n_out + chunk_size - 1) / chunk_size > n_chunks) return ZAMD_STREAM_ERROR;
     HIPCHK(hipSetDevice(e->device));
+    /* How many of the parts to use: segments beyond what fills the GPU a few times over gain nothing in the decode (it
+     * runs at the rate the whole GPU decodes at by then) and cost their 32 KiB each in the resolve step.  Measured on 1 MiB
+     * chunks: 8 192 chunks are best left whole, 4 096 cut in three or four, 512 in sixteen. */
+    uint32_t use = parts;
+    while (use > 1 && n_chunks * use > ZI_SPLIT_SEGMENTS) use--;
+    if (use < 2) return zamd_inflate_shard_dev(e, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk);
     /* the references of the resolve step are 30 bits wide: 32 768 segments to a round, each round on top of the output
      * of the one before it */
-    const uint64_t per_round = 32768u / parts;
+    const uint64_t per_round = 32768u / use;
     const uint64_t first = n_chunks < per_round ? n_chunks : per_round;
-    int rc = zi_ensure(e, first * parts, first * (uint64_t)chunk_size, true);
+    int rc = zi_ensure(e, first * use, first * (uint64_t)chunk_size, true);
     if (rc) return rc;
     double t_dec = 0, t_res = 0; int n_dec = 0, n_res = 0;
     for (uint64_t c0 = 0; c0 < n_chunks; c0 += per_round) {
@@ -974,11 +986,11 @@ extern "C" int zamd_inflate_split_dev(zamd_engine *e, const void *d_comp, uint64
         const uint64_t out_here = n_out > o0 ? n_out - o0 : 0;
         const uint8_t *head = c0 ? (const uint8_t *)d_out + o0 - 32768 : (const uint8_t *)d_head_window;
         hipLaunchKernelGGL(k_inf_setup_parts, dim3((uint32_t)((nc + 255) / 256)), dim3(256), 0, e->st[0], d_chunk_off + c0, nc, chunk_size, out_here, o0,
-                           d_head_window ? 32768u : 0u, d_splits + c0 * (parts - 1u), parts, e->inf->d_segs);
+                           d_head_window ? 32768u : 0u, d_splits + c0 * (parts - 1u), parts, use, e->inf->d_segs);
         int64_t bad = -1;
-        rc = zi_run(e, d_comp, comp_bytes, nc * parts, chunk_size, head, (uint8_t *)d_out + o0, out_here < nc * (uint64_t)chunk_size ? out_here : nc * (uint64_t)chunk_size,
-                    &bad, true, false, parts);
-        if (rc == ZAMD_DATA_ERROR) { e->inf->last_seg = (int64_t)c0 + bad / (int64_t)parts; if (bad_chunk) *bad_chunk = e->inf->last_seg; }
+        rc = zi_run(e, d_comp, comp_bytes, nc * use, chunk_size, head, (uint8_t *)d_out + o0, out_here < nc * (uint64_t)chunk_size ? out_here : nc * (uint64_t)chunk_size,
+                    &bad, true, false, use);
+        if (rc == ZAMD_DATA_ERROR) { e->inf->last_seg = (int64_t)c0 + bad / (int64_t)use; if (bad_chunk) *bad_chunk = e->inf->last_seg; }
         if (rc) return rc;
         t_dec += e->t_ms[7]; n_dec += e->t_n[7]; t_res += e->t_ms[8]; n_res += e->t_n[8];
     }
