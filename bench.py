@@ -283,7 +283,7 @@ def main():
             alg_bytes = (n / launches) * (1.0 + 1.0 / ratio)    # N_in + N_out of one launch's batch
             ach = alg_bytes / (avg_ms * 1e-3) / 1e9
             traffic, traffic_src = None, None
-            try:                    # HBM bytes of this kernel from the PMC passes of this round, if they were committed
+            try:                    # HBM bytes of this kernel from the committed PMC passes (the file names the workload and the commit it was taken at)
                 prof = json.load(open(os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")))
                 ent = [v for k, v in prof["kernels"].items() if k.startswith(kernel_name)][0]
                 if prof.get("workload", "l6_mixed") == args.workload:

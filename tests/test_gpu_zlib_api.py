@@ -463,6 +463,60 @@ def test_inflate_prime_starts_inside_a_byte():
     assert l.inflateEnd(C.byref(s)) == Z.Z_OK
 
 
+def test_inflate_prime_in_the_middle_of_a_stream(engine):
+    """inflatePrime at any time (inflate.c:230-250): bytes up to the one a block ends in, that block's last bits through
+    inflatePrime, the rest of the byte the same way, then the remaining bytes.  The reference build takes the same calls."""
+    import zlib_amd
+    data = O.corpus(600000, 0, 17)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    comp = c.compress(data) + c.flush()
+    # a block boundary inside a byte, from the engine's own segment interface
+    P = L1 = None
+    for frac in (3, 4, 5, 6, 7):
+        seg = dict(in_bit=0, in_end_bit=8 * len(comp), out_off=0, out_cap=1 << 22, win_avail=0, mode=zlib_amd.INF_BLOCKSTOP, stop_bit=len(comp) * frac)
+        res, _ = engine.inflate_segments(comp, [seg])
+        if res[0]["status"] == 2 and res[0]["end_bit"] % 8:
+            P, L1 = res[0]["end_bit"], res[0]["out_len"]
+            break
+    assert P is not None and 0 < L1 < len(data)
+    K, r = P // 8, P % 8
+    results = []
+    for l in (Z.lib(), Z.ref_lib()):
+        if l is None:
+            continue
+        l.inflatePrime.argtypes = [C.POINTER(Z.ZStream), C.c_int, C.c_int]
+        s = Z.ZStream()
+        assert l.inflateInit2_(C.byref(s), -15, Z.VERSION, Z.SZ) == 0
+        src = C.create_string_buffer(comp, len(comp))
+        obuf = C.create_string_buffer(len(data) + 16)
+        s.next_out, s.avail_out = C.addressof(obuf), len(data) + 16
+        s.next_in, s.avail_in = C.addressof(src), K
+        assert l.inflate(C.byref(s), Z.Z_SYNC_FLUSH) in (Z.Z_OK, Z.Z_BUF_ERROR)
+        assert s.avail_in == 0 and s.total_out <= L1
+        assert l.inflatePrime(C.byref(s), r, comp[K] & ((1 << r) - 1)) == Z.Z_OK            # the block's last bits
+        assert l.inflate(C.byref(s), Z.Z_SYNC_FLUSH) in (Z.Z_OK, Z.Z_BUF_ERROR)
+        assert s.total_out == L1 and obuf.raw[:L1] == data[:L1]                               # exactly up to the block's end
+        assert l.inflatePrime(C.byref(s), 8 - r, comp[K] >> r) == Z.Z_OK                      # the rest of that byte
+        s.next_in, s.avail_in = C.addressof(src) + K + 1, len(comp) - K - 1
+        assert l.inflate(C.byref(s), Z.Z_FINISH) == Z.Z_STREAM_END
+        assert s.total_out == len(data) and obuf.raw[:len(data)] == data
+        results.append((s.total_in, s.total_out))
+        assert l.inflateEnd(C.byref(s)) == Z.Z_OK
+    assert len(set(results)) == 1
+    # bits that leave a byte unfinished, then input: one buffer cannot hold that, and says so
+    l = Z.lib()
+    s = Z.ZStream()
+    assert l.inflateInit2_(C.byref(s), -15, Z.VERSION, Z.SZ) == 0
+    src = C.create_string_buffer(comp, len(comp))
+    obuf = C.create_string_buffer(len(data) + 16)
+    s.next_out, s.avail_out, s.next_in, s.avail_in = C.addressof(obuf), len(data) + 16, C.addressof(src), K
+    assert l.inflate(C.byref(s), Z.Z_SYNC_FLUSH) in (Z.Z_OK, Z.Z_BUF_ERROR)
+    assert l.inflatePrime(C.byref(s), 3, 5) == Z.Z_OK
+    s.next_in, s.avail_in = C.addressof(src) + K, 10
+    assert l.inflate(C.byref(s), Z.Z_SYNC_FLUSH) == Z.Z_STREAM_ERROR and b"inflatePrime" in s.msg
+    assert l.inflateEnd(C.byref(s)) == Z.Z_OK
+
+
 def test_deflate_prime_puts_bits_in_front():
     """deflatePrime (deflate.c:464-487): whole bytes go out at once, the rest shifts the first block."""
     data = O.corpus(200000, 4, 93)

@@ -977,12 +977,13 @@ struct IState {
     uint32_t dictid;
     uint64_t out_batch;
     uint64_t prime_hold; unsigned prime_bits;   // inflatePrime bits waiting in front of the first input byte
+    unsigned tail_partial;          // inflatePrime bits behind buffered input: valid low bits of the last byte of `in` (0: it is whole)
     Words hints; size_t hint_pos;   // chunk index of the deflate data ahead (zamd_inflate_index_hint): compressed bytes, inflated bytes per chunk
     Longs hint_splits; unsigned hint_per;   // and hint_per split records per chunk (zamd_inflate_index_hint_splits), or none
     uint64_t hinted_chunks;         // chunks placed by their index entries since inflateInit (zamd_inflate_hinted_chunks)
     size_t call_taken;              // bytes the current inflate() call has moved from next_in to the end of `in`
     explicit IState(z_streamp strm) : hdr(ZAlloc<uint8_t>(strm)), in(ZAlloc<uint8_t>(strm)), cands(ZAlloc<uint64_t>(strm)), out(ZAlloc<uint8_t>(strm)),
-                                      hist(ZAlloc<uint8_t>(strm)), hints(ZAlloc<uint32_t>(strm)), hint_splits(ZAlloc<uint64_t>(strm)), hint_per(0), hinted_chunks(0) {}
+                                      hist(ZAlloc<uint8_t>(strm)), hints(ZAlloc<uint32_t>(strm)), hint_splits(ZAlloc<uint64_t>(strm)), hint_per(0), hinted_chunks(0) { tail_partial = 0; }
 };
 
 // Hands the bytes at the end of `in` that the current call took (at most `want` of them) back to the caller.
@@ -1237,7 +1238,9 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     Longs view_cands(s->cands.get_allocator()); size_t view_scanned = 0;
     Longs &cands = view ? view_cands : s->cands;
     size_t &scanned = view ? view_scanned : s->scanned;
-    if (in_n * 8ull <= s->bit_off) return view ? NO_PROGRESS : Z_OK;
+    // bits that inflatePrime put behind the buffered input end inside the last byte
+    const uint64_t end_bits = in_n * 8ull - ((!view && s->tail_partial) ? 8u - s->tail_partial : 0u);
+    if (end_bits <= s->bit_off) { if (view) return NO_PROGRESS; s->tried = in_n; return Z_OK; }
     Trace tr;
     LaneLock lk;
     zamd_engine *e = engine_locked();
@@ -1253,7 +1256,6 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         tr.lap("upload");
         return Z_OK;
     };
-    const uint64_t end_bits = in_n * 8ull;
     // what a round may produce: the output batch, or what the caller's buffer takes when the round can write straight into it
     uint64_t out_batch = s->out_batch;
     if (s->out.size() == s->out_pos && strm->avail_out >= (64u << 20) && strm->avail_out < out_batch) out_batch = strm->avail_out;
@@ -1560,6 +1562,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     if (view) { strm->next_in += drop; strm->avail_in -= (uInt)drop; strm->total_in += drop; }
     else {
         s->in.erase(s->in.begin(), s->in.begin() + drop);
+        if (s->in.empty()) s->tail_partial = 0;
         Longs keep(cands.get_allocator());
         for (uint64_t c : cands) if (c > drop) keep.push_back(c - drop);
         cands.swap(keep);
@@ -1580,7 +1583,7 @@ int istate_reset(z_streamp strm, IState *s, bool keep_window) {
     s->head = Z_NULL;
     s->hdr.clear(); s->in.clear(); s->cands.clear(); s->out.clear();
     s->bit_off = 0; s->scanned = 0; s->tried = 0; s->out_pos = 0; s->check = 0; s->dictid = 0;
-    s->prime_hold = 0; s->prime_bits = 0;
+    s->prime_hold = 0; s->prime_bits = 0; s->tail_partial = 0;
     drop_hints(s);
     if (!keep_window) s->hist.clear();
     return Z_OK;
@@ -1719,6 +1722,10 @@ static int inflate_body(z_streamp strm, int flush) {
                 if (rc != NO_PROGRESS) continue;
                 tried_all = n == strm->avail_in;            // not one whole block in there: buffer it and wait for more
             }
+            if (s->tail_partial && strm->avail_in) {
+                strm->msg = "input behind inflatePrime bits that do not complete a byte";
+                return Z_STREAM_ERROR;
+            }
             const size_t before = s->in.size();
             uint64_t room = (512ull << 20) > before ? (512ull << 20) - before : 0;
             uint64_t take = strm->avail_in < room ? strm->avail_in : room;
@@ -1849,21 +1856,37 @@ static int inflateCopy_body(z_streamp dest, z_streamp source) {
 }
 int inflateCopy(z_streamp dest, z_streamp source) { return guarded(dest, [&] { return inflateCopy_body(dest, source); }); }
 
-int inflatePrime(z_streamp strm, int bits, int value) {     // inflate.c:230-250
+static int inflatePrime_body(z_streamp strm, int bits, int value) {     // inflate.c:230-250
     IState *s = istate(strm);
     if (!s) return Z_STREAM_ERROR;
     if (bits < 0) { s->prime_hold = 0; s->prime_bits = 0; return Z_OK; }
     if (bits > 16 || s->prime_bits + (unsigned)bits > 32) return Z_STREAM_ERROR;
-    // Bits can be put in front of deflate data only, and only while no input is buffered
-    // (the reference's bit accumulator is a few bits; here whole batches wait).
-    if (s->mode != IM_BODY || !s->in.empty()) {
-        strm->msg = "inflatePrime is supported on deflate data before its first input only";
+    if (s->mode != IM_BODY) {
+        strm->msg = "inflatePrime is supported on deflate data only";
         return Z_STREAM_ERROR;
     }
-    s->prime_hold += (uint64_t)((unsigned)value & ((1u << bits) - 1u)) << s->prime_bits;
+    const uint32_t v = (unsigned)value & ((1u << bits) - 1u);
+    if (!s->in.empty()) {
+        // In the middle of a stream, with input waiting for the rest of its block: the bits go behind that input (the
+        // reference puts them into its bit accumulator, in front of the bytes that have not been handed over yet).  The last
+        // byte of `in` may then be a partial one; input can follow once further bits have completed it, because stored
+        // blocks align to the input's own byte boundaries and one buffer has only one set of those.
+        uint32_t left = (uint32_t)bits, val = v;
+        while (left) {
+            if (s->tail_partial == 0) { s->in.push_back(0); }
+            const unsigned have = s->tail_partial, take = 8u - have < left ? 8u - have : left;
+            s->in.back() = (uint8_t)(s->in.back() | ((val & ((1u << take) - 1u)) << have));
+            s->tail_partial = (have + take) & 7u;
+            val >>= take; left -= take;
+        }
+        s->tried = 0;                      // there is something new to look at
+        return Z_OK;
+    }
+    s->prime_hold += (uint64_t)v << s->prime_bits;
     s->prime_bits += (unsigned)bits;
     return Z_OK;
 }
+int inflatePrime(z_streamp strm, int bits, int value) { return guarded(strm, [&] { return inflatePrime_body(strm, bits, value); }); }
 
 int inflateUndermine(z_streamp strm, int) {      // inflate.c:1485-1500 without INFLATE_ALLOW_INVALID_DISTANCE_TOOFAR_ARRR
     if (!istate(strm)) return Z_STREAM_ERROR;
