@@ -715,6 +715,65 @@ __global__ __launch_bounds__(256) void k_inf_ref_jump(uint32_t *ref, uint64_t n)
     const uint32_t r = ref[i];
     if (!(r >> 30)) ref[i] = __hip_atomic_load(ref + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+/* The same for chunks that were cut into `use` parts, in three steps that touch most slots twice instead of once per
+ * round: (1) part k = 1, 2, ... of every chunk takes over what its references into earlier parts of the SAME chunk hold,
+ * which by then are bytes or references into earlier chunks (k_inf_ref_local, one launch per k); (2) the jump rounds run
+ * over the slots of each chunk's last 32 KiB only, the only slots later chunks refer to (k_inf_ref_jump_last); (3)
+ * every other slot takes over what its reference — into such a last 32 KiB — holds now (k_inf_ref_rest). */
+__global__ __launch_bounds__(1024) void k_inf_ref_local(uint32_t *ref, uint32_t use, uint32_t k)
+{
+    const uint32_t chunk = blockIdx.x >> 5, si = chunk * use + k, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
+    const uint64_t i = (uint64_t)si * 32768u + e;
+    const uint32_t r = ref[i];
+    if (r >> 30) return;
+    if ((r >> 15) / use != chunk) return;                /* into an earlier chunk already */
+    ref[i] = ref[r];                                     /* an earlier part: not written by this launch */
+}
+/* does slot e of segment S hold a byte of the last 32 KiB of its chunk (which ends at chunk_end) */
+__device__ __forceinline__ bool zi_in_last_window(const ZiSeg &S, uint32_t e, uint64_t chunk_end)
+{
+    const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
+    return e < tl && S.out_off + S.out_len - tl + e + 32768 >= chunk_end;
+}
+/* The groups of 1 024 slots that hold bytes of their chunk's last 32 KiB, listed once (a launch over all groups in every
+ * round costs more in groups that have nothing to do than the rounds save) */
+__global__ __launch_bounds__(256) void k_inf_ref_last_list(const ZiSeg *segs, uint64_t ngroups, uint32_t use, uint32_t chunk_size, uint64_t total,
+                                                           uint2 *list, uint32_t cap, uint32_t *count)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= ngroups) return;
+    const uint32_t si = (uint32_t)(g >> 5), e0 = (uint32_t)(g & 31u) * 1024u;
+    const ZiSeg S = segs[si];
+    const uint64_t ce = (uint64_t)(si / use + 1u) * chunk_size, chunk_end = ce < total ? ce : total;
+    const uint64_t tl = S.out_len < 32768 ? S.out_len : 32768;
+    if (e0 >= tl) return;
+    const uint32_t e1 = (uint32_t)(e0 + 1024u < tl ? e0 + 1024u : tl);               /* slots [e0, e1) hold bytes */
+    if (!zi_in_last_window(S, e1 - 1u, chunk_end)) return;
+    /* the first of them that lies in the window (positions ascend with the slots) */
+    const uint64_t p0 = S.out_off + S.out_len - tl + e0;
+    const uint32_t lo = p0 + 32768 >= chunk_end ? 0u : (uint32_t)(chunk_end - 32768 - p0);
+    const uint32_t at = atomicAdd(count, 1u);
+    if (at < cap) list[at] = make_uint2(si * 32768u + e0, lo | ((e1 - e0) << 16));  /* first slot of the group; the range of its slots to look at */
+}
+__global__ __launch_bounds__(1024) void k_inf_ref_jump_last(uint32_t *ref, const uint2 *list, const uint32_t *count)
+{
+    if (blockIdx.x >= *count) return;
+    const uint2 g = list[blockIdx.x];
+    if (threadIdx.x < (g.y & 0xffffu) || threadIdx.x >= (g.y >> 16)) return;
+    const uint32_t i = g.x + threadIdx.x;
+    const uint32_t r = ref[i];
+    if (!(r >> 30)) ref[i] = __hip_atomic_load(ref + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(1024) void k_inf_ref_rest(const ZiSeg *segs, uint32_t *ref, uint32_t use, uint32_t chunk_size, uint64_t total)
+{
+    const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
+    const ZiSeg S = segs[si];
+    const uint64_t ce = (uint64_t)(si / use + 1u) * chunk_size, chunk_end = ce < total ? ce : total;
+    if (zi_in_last_window(S, e, chunk_end)) return;
+    const uint64_t i = (uint64_t)si * 32768u + e;
+    const uint32_t r = ref[i];
+    if (!(r >> 30)) ref[i] = ref[r];                     /* a slot of a last window: resolved, and not written by this launch */
+}
 __global__ __launch_bounds__(1024) void k_inf_ref_write(const ZiSeg *segs, const uint32_t *ref, uint8_t *out8, const uint8_t *head)
 {
     const uint32_t si = blockIdx.x >> 5, e = (blockIdx.x & 31u) * 1024u + threadIdx.x;
@@ -797,6 +856,7 @@ struct ZiState {
     uint16_t *d_stage = nullptr; uint64_t stage_cap = 0;     /* elements */
     uint32_t *d_marks = nullptr; uint32_t *d_mlist = nullptr;
     unsigned long long *d_res = nullptr;
+    uint2 *d_flist = nullptr; uint32_t flist_cap = 0;        /* groups of slots in the chunks' last windows, and their count behind them */
     uint32_t last_status = 0; int64_t last_seg = -1;
     uint64_t *d_scan = nullptr; uint32_t scan_cap = 0;          /* zamd_find_sync_dev's result list */
     /* a sharded inflate between its begin and finish calls */
@@ -807,7 +867,7 @@ static void zi_free(zamd_engine *e)
 {
     ZiState *z = e->inf;
     if (!z) return;
-    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res); hipFree(z->d_scan);
+    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res); hipFree(z->d_flist); hipFree(z->d_scan);
     delete z; e->inf = nullptr;
 }
 
@@ -873,10 +933,34 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
         if (regular_tails && nseg <= 32768 && (defer || !getenv("ZAMD_INF_SERIAL_TAILS"))) {
             const uint64_t nref = nseg * 32768ull;
             hipLaunchKernelGGL(k_inf_ref_init, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, defer ? (const uint8_t *)nullptr : (const uint8_t *)d_head, z->d_mlist);
-            uint32_t rounds = 1;
-            while ((1ull << rounds) < nseg) rounds++;
-            for (uint32_t r = 0; r <= rounds; r++)
-                hipLaunchKernelGGL(k_inf_ref_jump, dim3((uint32_t)((nref + 255) / 256)), dim3(256), 0, s, z->d_mlist, nref);
+            static const bool flat_only = getenv("ZAMD_INF_FLAT_RESOLVE") != nullptr;      /* tests and measurements */
+            if (parts > 1 && chunk_size >= 32768 && !defer && !flat_only) {
+                const uint32_t nchunks = (uint32_t)(nseg / parts);
+                for (uint32_t k = 1; k < parts; k++)
+                    hipLaunchKernelGGL(k_inf_ref_local, dim3(nchunks * 32u), dim3(1024), 0, s, z->d_mlist, parts, k);
+                /* a chunk's last 32 KiB lie in 32 groups of 1 024 slots, plus one for every segment border they cross */
+                const uint32_t cap = nchunks * (33u + parts);
+                if (z->flist_cap < cap + 1u) {
+                    hipFree(z->d_flist); z->d_flist = nullptr; z->flist_cap = 0;
+                    if (hipMalloc((void **)&z->d_flist, ((uint64_t)cap + 1u) * sizeof(uint2)) != hipSuccess) return ZAMD_MEM_ERROR;
+                    z->flist_cap = cap + 1u;
+                }
+                uint32_t *const d_count = (uint32_t *)(z->d_flist + cap);
+                HIPCHK(hipMemsetAsync(d_count, 0, 4, s));
+                const uint64_t ngroups = nseg * 32ull;
+                hipLaunchKernelGGL(k_inf_ref_last_list, dim3((uint32_t)((ngroups + 255) / 256)), dim3(256), 0, s, z->d_segs, ngroups, parts, chunk_size, out_bytes,
+                                   z->d_flist, cap, d_count);
+                uint32_t rounds = 1;
+                while ((1ull << rounds) < nchunks) rounds++;
+                for (uint32_t r = 0; r <= rounds; r++)
+                    hipLaunchKernelGGL(k_inf_ref_jump_last, dim3(cap), dim3(1024), 0, s, z->d_mlist, z->d_flist, d_count);
+                hipLaunchKernelGGL(k_inf_ref_rest, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, parts, chunk_size, out_bytes);
+            } else {
+                uint32_t rounds = 1;
+                while ((1ull << rounds) < nseg) rounds++;
+                for (uint32_t r = 0; r <= rounds; r++)
+                    hipLaunchKernelGGL(k_inf_ref_jump, dim3((uint32_t)((nref + 255) / 256)), dim3(256), 0, s, z->d_mlist, nref);
+            }
             if (defer) {
                 tm_end(e, s, slot);
                 HIPCHK(hipGetLastError());
@@ -970,8 +1054,9 @@ extern "C" int zamd_inflate_split_dev(zamd_engine *e, const void *d_comp, uint64
     /* How many of the parts to use: segments beyond what fills the GPU a few times over gain nothing in the decode (it
      * runs at the rate the whole GPU decodes at by then) and cost their 32 KiB each in the resolve step.  Measured on 1 MiB
      * chunks: 8 192 chunks are best left whole, 4 096 cut in three or four, 512 in sixteen. */
+    static const uint64_t seg_limit = getenv("ZAMD_INF_SPLIT_SEGMENTS") ? strtoull(getenv("ZAMD_INF_SPLIT_SEGMENTS"), nullptr, 10) : ZI_SPLIT_SEGMENTS;
     uint32_t use = parts;
-    while (use > 1 && n_chunks * use > ZI_SPLIT_SEGMENTS) use--;
+    while (use > 1 && n_chunks * use > seg_limit) use--;
     if (use < 2) return zamd_inflate_shard_dev(e, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk);
     /* the references of the resolve step are 30 bits wide: 32 768 segments to a round, each round on top of the output
      * of the one before it */
