@@ -7,7 +7,8 @@
  * One wavefront decodes one segment (k_inf_decode):
  *   - the compressed bytes are held 2 x 256 B at a time in two VGPRs (one dword
  *     per lane) and picked out with v_readlane, so the bit reader makes no
- *     memory access per symbol;
+ *     memory access per symbol (the speculative decode of 64 bit offsets at once
+ *     reads a copy of the same 512 bytes in LDS, three dwords per lane);
  *   - Huffman tables are per-wave LDS images: a 2^9 (literal/length) or 2^8
  *     (distance) first-level table of u16 {symbol, length}; longer codes fall
  *     back to the canonical first-code search;
@@ -34,6 +35,10 @@
 #define ZI_ROOT_D 8
 #endif
 #define ZI_ROOT_C 7
+#ifndef ZI_SPAN_REGS
+#define ZI_SPAN_LDS 1        /* zi_span's lanes pick their input dwords from a copy of the window in LDS: three reads instead of ten v_readlane and
+                              * the selects around them (text 2 GiB: decode 45.2 -> 40.6 ms, mixed 8 GiB 136.2 -> 134.3; -DZI_SPAN_REGS builds the other form) */
+#endif
 #define ZI_MARK   256u       /* first marker value: byte 0 of the preceding 32 KiB */
 #ifndef ZI_STAGE
 #define ZI_STAGE  512u       /* elements of the per-wave output stage (>= 258) */
@@ -124,9 +129,15 @@ struct ZiLds {
     uint8_t lens[320 + 8];
     uint8_t cl[20 + 4];
     uint16_t stage[ZI_STAGE];      /* output of the tokens being written, before it goes to memory */
+#ifdef ZI_SPAN_LDS
+    uint32_t ring[128];            /* the 512 input bytes the two window registers hold, where zi_span's lanes pick their own dwords */
+#endif
 };
 
 struct ZiBits {
+#ifdef ZI_SPAN_LDS
+    uint32_t *ring;
+#endif
     const uint32_t *base; uint64_t ndw;   /* readable dwords */
     uint32_t cur, nxt;                    /* per lane: dword wbase+lane, wbase+64+lane */
     uint64_t wbase;
@@ -141,6 +152,9 @@ __device__ __forceinline__ void zi_bits_init(ZiBits &b, const uint32_t *base, ui
     b.wbase = (bitpos >> 5) & ~63ull;
     b.cur = zi_ldw(b, b.wbase + lane);
     b.nxt = zi_ldw(b, b.wbase + 64 + lane);
+#ifdef ZI_SPAN_LDS
+    b.ring[((uint32_t)b.wbase + lane) & 127u] = b.cur; b.ring[((uint32_t)b.wbase + 64u + lane) & 127u] = b.nxt;
+#endif
 }
 
 /* >= 33 valid bits at the current position (wave-uniform result) */
@@ -154,6 +168,9 @@ __device__ __forceinline__ uint64_t zi_peek(ZiBits &b, uint32_t lane)
             b.cur = zi_ldw(b, b.wbase + lane); b.nxt = zi_ldw(b, b.wbase + 64 + lane);
             dw = (b.bitpos >> 5) - b.wbase;
         }
+#ifdef ZI_SPAN_LDS
+        b.ring[((uint32_t)b.wbase + lane) & 127u] = b.cur; b.ring[((uint32_t)b.wbase + 64u + lane) & 127u] = b.nxt;
+#endif
     }
     uint32_t d0 = (uint32_t)dw;
     uint32_t lo = __builtin_amdgcn_readlane(b.cur, d0);
@@ -198,6 +215,11 @@ __device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, c
 {
     b.bitpos = sb;
     (void)zi_peek(b, lane);                              /* brings the window up to sb */
+#ifdef ZI_SPAN_LDS
+    const uint32_t t = ((uint32_t)sb & 31u) + lane, kk = t >> 5, sh = t & 31u;
+    const uint32_t dwi = (uint32_t)(sb >> 5) + kk;        /* the window holds dwords wbase .. wbase + 127, and sb lies in its first half */
+    const uint32_t A = b.ring[dwi & 127u], Bv = b.ring[(dwi + 1u) & 127u], C = b.ring[(dwi + 2u) & 127u];
+#else
     const uint32_t d0 = (uint32_t)((sb >> 5) - b.wbase);  /* 0..63 */
     uint32_t D[5];
 #pragma unroll
@@ -209,6 +231,7 @@ __device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, c
     const uint32_t A = kk == 0 ? D[0] : kk == 1 ? D[1] : D[2];
     const uint32_t Bv = kk == 0 ? D[1] : kk == 1 ? D[2] : D[3];
     const uint32_t C = kk == 0 ? D[2] : kk == 1 ? D[3] : D[4];
+#endif
     const uint32_t lo = __builtin_amdgcn_alignbit(Bv, A, sh), hi = __builtin_amdgcn_alignbit(C, Bv, sh);
     const uint64_t W = ((uint64_t)hi << 32) | lo;
     const uint32_t e1 = lut_l[lo & ((1u << ZI_ROOT_L) - 1u)];
@@ -307,6 +330,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
     ZiSeg S = segs[si];
     const uint64_t end_bits = S.in_end_bit;
     ZiBits B;
+#ifdef ZI_SPAN_LDS
+    B.ring = L.ring;
+#endif
     zi_bits_init(B, (const uint32_t *)comp, (comp_bytes + 3) >> 2, S.in_bit, lane);
     ZiTab TL{L.lut_l, L.sorted_l, L.meta[0][0], L.meta[0][1], L.meta[0][2], ZI_T_L};
     ZiTab TD{L.lut_d, L.sorted_d, L.meta[1][0], L.meta[1][1], L.meta[1][2], ZI_T_D};
