@@ -238,6 +238,14 @@ typedef struct zamd_inflate_seg {
 #define ZAMD_INF_BLOCKSTOP 4u           /* status 2 (as for a sync marker) when a block ends at or behind stop_bit */
 int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, zamd_inflate_seg *segs, uint64_t nseg,
                               const void *d_head_window, void *d_out, uint64_t out_bytes);
+/* Block boundaries from a counting pass: the next zamd_inflate_segments_dev call with d_out == NULL (and no other)
+ * fills h_marks (host, nseg rows of ZAMD_INF_MARKS entries) with boundaries between the blocks of every segment, as
+ * (bits from the segment's in_bit) << 32 | bytes of output in front of the boundary, ascending, unused entries 0: one
+ * about every step_bytes of output, and further apart once a segment has reported ZAMD_INF_MARKS - 1 of them (every
+ * other one is then dropped).  With them the pass that writes the output can cut a segment into parts (the access
+ * points examples/zran.c:195-223 collects with Z_BLOCK).  h_marks == NULL withdraws the request. */
+#define ZAMD_INF_MARKS 16u
+int zamd_inflate_block_marks(zamd_engine *e, unsigned long long *h_marks, uint32_t step_bytes);
 /* Offsets just behind every 00 00 FF FF in d_in[from, n) (the pattern inflateSync looks for,
  * inflate.c:1354-1375): candidate starting points for zamd_inflate_segments_dev.  h_list (host)
  * receives at most cap offsets in no particular order; *count above cap means the list is

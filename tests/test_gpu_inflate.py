@@ -163,6 +163,46 @@ def test_segments_stop_at_sync_markers_and_chain(engine):
     assert out == data
 
 
+@pytest.mark.parametrize("n,step", [(3000000, 131072), (3000000, 4096), (200000, 1 << 20), (9000000, 65536)])
+def test_counting_pass_reports_block_marks(engine, n, step):
+    """The block marks of a counting pass (zamd_inflate_block_marks) are boundaries between blocks: cut there, the
+    segment inflates part by part to the same bytes (the parts' windows are the output in front of them).  A segment with
+    more blocks than a row holds reports marks spread over all of it; the request holds for one call."""
+    data = O.corpus(n, 4, 77)
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    half = n // 2
+    comp = c.compress(data[:half]) + c.flush(zlib.Z_SYNC_FLUSH)
+    cut = len(comp)
+    comp += c.compress(data[half:]) + c.flush()
+    segs = [dict(in_bit=0, in_end_bit=8 * len(comp), out_off=0, out_cap=1 << 30, win_avail=0, mode=zlib_amd.INF_SYNCSTOP),
+            dict(in_bit=8 * cut, in_end_bit=8 * len(comp), out_off=0, out_cap=1 << 30, win_avail=32768, mode=zlib_amd.INF_SYNCSTOP)]
+    res, _ = engine.inflate_segments(comp, segs, mark_step=step)
+    assert [r["status"] for r in res] == [2, 1] and [r["out_len"] for r in res] == [half, n - half]
+    parts, base = [], 0
+    for s, r in zip(segs, res):
+        marks = r["marks"]
+        assert len(marks) <= zlib_amd.INF_MARKS - 1
+        assert marks == sorted(set(marks)) and all(0 < o <= r["out_len"] and 0 < b < r["end_bit"] - s["in_bit"] for b, o in marks)
+        marks = [m for m in marks if m[1] < r["out_len"]]        # the boundary in front of a closing empty block cuts nothing off
+        if r["out_len"] >= 4 * step and step >= 65536:
+            assert len(marks) >= 3
+        if marks and len(marks) < zlib_amd.INF_MARKS - 1 and step >= 65536:        # nothing dropped: one mark per step of output at least
+            assert marks[0][1] >= step and all(b[1] - a[1] >= step for a, b in zip(marks, marks[1:]))
+        if len(marks) >= 7:                            # spread over the whole segment
+            assert marks[-1][1] > r["out_len"] // 2
+        edges = [(0, 0)] + marks + [(r["end_bit"] - s["in_bit"], r["out_len"])]
+        for (b0, o0), (b1, o1) in zip(edges, edges[1:]):
+            parts.append(dict(in_bit=s["in_bit"] + b0, in_end_bit=s["in_bit"] + b1, out_off=base + o0, out_cap=o1 - o0,
+                              win_avail=min(32768, base + o0), mode=zlib_amd.INF_EXACT))
+        base += r["out_len"]
+    res2, out = engine.inflate_segments(comp, parts, out_bytes=n)
+    assert all(r["status"] in (0, 1) for r in res2), res2
+    assert out == data
+    # the next counting pass was not asked for marks
+    res3, _ = engine.inflate_segments(comp, segs)
+    assert "marks" not in res3[0] and [r["out_len"] for r in res3] == [half, n - half]
+
+
 def test_truncated_input_reports_last_complete_block(engine):
     data = O.corpus(400000, 0, 2)
     c = zlib.compressobj(6, zlib.DEFLATED, -15)

@@ -28,6 +28,9 @@ class ZamdError(RuntimeError):
         self.code, self.msg, self.segment = code, msg, segment
 
 
+INF_MARKS = 16      # ZAMD_INF_MARKS: entries in a segment's row of block marks
+
+
 class InflateSeg(C.Structure):
     """zamd_inflate_seg of include/zamd.h."""
     _fields_ = [("in_bit", C.c_uint64), ("in_end_bit", C.c_uint64), ("out_off", C.c_uint64), ("out_cap", C.c_uint64),
@@ -105,6 +108,8 @@ def load_library() -> C.CDLL:
     lib.zamd_engine_set_streams.restype = i32
     lib.zamd_inflate_segments_dev.argtypes = [vp, vp, u64, C.POINTER(InflateSeg), u64, vp, vp, u64]
     lib.zamd_inflate_segments_dev.restype = i32
+    lib.zamd_inflate_block_marks.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_uint32]
+    lib.zamd_inflate_block_marks.restype = i32
     lib.zamd_inflate_message.argtypes = [u32]
     lib.zamd_inflate_message.restype = C.c_char_p
     lib.zamd_inflate_last_error.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(u32)]
@@ -520,10 +525,16 @@ class Engine:
         finally:
             d.free()
 
-    def inflate_segments(self, stream, segs, *, out_bytes: int = 0, head_window=None):
+    def inflate_segments(self, stream, segs, *, out_bytes: int = 0, head_window=None, mark_step: int = 0):
         """zamd_inflate_segments_dev on host bytes.  segs: list of dicts with the input fields of InflateSeg.
-        Returns (list of result dicts, output bytes or None when out_bytes == 0)."""
+        Returns (list of result dicts, output bytes or None when out_bytes == 0).  mark_step (counting passes:
+        out_bytes == 0) asks for block marks (zamd_inflate_block_marks); every result dict then has "marks", the
+        segment's list of (bits from in_bit, bytes of output) pairs."""
         arr = (InflateSeg * len(segs))()
+        marks = None
+        if mark_step:
+            marks = (C.c_ulonglong * (len(segs) * INF_MARKS))()
+            _chk(self.lib.zamd_inflate_block_marks(self.handle, marks, mark_step), "zamd_inflate_block_marks")
         for a, sdict in zip(arr, segs):
             for k, v in sdict.items():
                 setattr(a, k, v)
@@ -538,8 +549,11 @@ class Engine:
                                                     d_head.ptr if d_head else None, d_out.ptr if d_out else None, out_bytes),
                  "zamd_inflate_segments_dev")
             res = [{f[0]: getattr(a, f[0]) for f in InflateSeg._fields_} for a in arr]
-            for r in res:
+            for i, r in enumerate(res):
                 r["msg"] = self.lib.zamd_inflate_message(r["status"]).decode()
+                if marks is not None:
+                    row = marks[i * INF_MARKS:(i + 1) * INF_MARKS]
+                    r["marks"] = [(int(v) >> 32, int(v) & 0xffffffff) for v in row if v]
             return res, (bytes(d_out.download(out_bytes)) if d_out else None)
         finally:
             d_comp.free()

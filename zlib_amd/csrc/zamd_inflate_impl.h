@@ -46,6 +46,7 @@
 #ifndef ZI_SPLIT_SEGMENTS
 #define ZI_SPLIT_SEGMENTS 14336u   /* zamd_inflate_split_dev cuts chunks into parts while that many segments are not exceeded */
 #endif
+#define ZI_MARKS  15u        /* block boundaries a segment can report (zamd_inflate_block_marks); a row of the result has one more entry */
 #define ZI_EMPTY  0xffffu    /* stage element not produced yet (no byte or marker has this value) */
 __constant__ uint8_t zi_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};   /* inflate.c:608-609 */
 
@@ -132,6 +133,10 @@ struct ZiLds {
 #ifdef ZI_SPAN_LDS
     uint32_t ring[128];            /* the 512 input bytes the two window registers hold, where zi_span's lanes pick their own dwords */
 #endif
+    /* block marks of a counting pass (zi_mark): the records, how many, the spacing and the output position the next one waits for */
+    uint64_t bm[ZI_MARKS + 1];
+    uint64_t bm_next;
+    uint32_t bm_n, bm_step;
 };
 
 struct ZiBits {
@@ -315,19 +320,44 @@ __device__ __forceinline__ uint32_t zi_slow(const ZiTab &T, uint32_t bits, uint3
     return 0u;
 }
 
+/* Notes the block boundary at `rel_bit` bits behind the segment's start, where `pos` bytes have been produced: one record
+ * every bm_step bytes of output at least.  A full list keeps every other record and doubles the spacing, so a segment
+ * of any length reports boundaries spread over all of it.  All values are the same in every lane. */
+__device__ __noinline__ void zi_mark(ZiLds &L, uint64_t rel_bit, uint64_t pos, uint32_t lane)
+{
+    if ((rel_bit | pos) >> 32) return;
+    uint32_t n = L.bm_n, step = L.bm_step;
+    if (n == ZI_MARKS) {
+        const uint64_t v = lane < ZI_MARKS / 2u ? L.bm[2u * lane + 1u] : 0ull;
+        __syncthreads();
+        if (lane < ZI_MARKS / 2u) L.bm[lane] = v;
+        n = ZI_MARKS / 2u;
+        step = step < 0x40000000u ? step * 2u : step;
+    }
+    __syncthreads();
+    if (lane == 0) { L.bm[n] = (rel_bit << 32) | pos; L.bm_n = n + 1u; L.bm_step = step; L.bm_next = pos + step; }
+    __syncthreads();
+}
+
 template <bool WRITE>
 /* registers, not LDS, set the wavefronts per SIMD: 84 registers allow 5; held to 80 (two spilled values) 6 fit and decode
  * 3 % faster, held to 72 (five spills) 7 fit and it is slower */
 #ifndef ZI_WAVES_PER_SIMD
 #define ZI_WAVES_PER_SIMD 6
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER_SIMD, ZI_WAVES_PER_SIMD))) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER_SIMD, ZI_WAVES_PER_SIMD))) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16,
+                                                                                                                                 uint64_t *bmarks, uint32_t mark_step)
 {
     __shared__ ZiLds L;
     const uint32_t lane = threadIdx.x;
     const uint32_t si = blockIdx.x;
     if (si >= nseg) return;
     ZiSeg S = segs[si];
+    const bool marking = !WRITE && bmarks != nullptr;        /* only a counting pass reports block marks */
+    if (marking) {
+        if (lane == 0) { L.bm_n = 0; L.bm_step = mark_step; L.bm_next = mark_step; }
+        __syncthreads();
+    }
     const uint64_t end_bits = S.in_end_bit;
     ZiBits B;
 #ifdef ZI_SPAN_LDS
@@ -610,12 +640,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
         if (B.bitpos > end_bits) { status = ZI_NEED_INPUT; break; }
         good_bit = B.bitpos; good_pos = pos;
         if (last) { final_seen = 1; status = ZI_OK_FINAL; break; }
+        if (marking && pos >= L.bm_next) zi_mark(L, good_bit - S.in_bit, pos, lane);
         if (empty_stored && (S.mode & ZI_MODE_SYNCSTOP)) { status = ZI_OK_SYNC; break; }
         if ((S.mode & ZI_MODE_BLOCKSTOP) && B.bitpos >= S.stop_bit) { status = ZI_OK_SYNC; break; }
     }
     if ((S.mode & ZI_MODE_EXACT) && status < 3 && good_pos != S.out_cap) status = ZI_ERR_LENGTH;
     if (lane == 0) {
         segs[si].out_len = good_pos; segs[si].end_bit = good_bit; segs[si].status = status; segs[si].final_seen = final_seen;
+    }
+    if (marking) {
+        __syncthreads();
+        if (lane <= ZI_MARKS) bmarks[(uint64_t)si * (ZI_MARKS + 1u) + lane] = lane < L.bm_n ? L.bm[lane] : 0ull;
     }
 }
 
@@ -885,6 +920,8 @@ struct ZiState {
     uint2 *d_flist = nullptr; uint32_t flist_cap = 0;        /* groups of slots in the chunks' last windows, and their count behind them */
     uint32_t last_status = 0; int64_t last_seg = -1;
     uint64_t *d_scan = nullptr; uint32_t scan_cap = 0;          /* zamd_find_sync_dev's result list */
+    uint64_t *d_bmarks = nullptr; uint64_t bmarks_cap = 0;      /* block marks of a counting pass, a row per segment */
+    unsigned long long *h_bmarks = nullptr; uint32_t bmark_step = 0;     /* where the next counting pass is to leave them (zamd_inflate_block_marks) */
     /* a sharded inflate between its begin and finish calls */
     bool pending = false; bool pend_has_head = false; uint64_t pend_nseg = 0, pend_out_bytes = 0; uint32_t pend_chunk = 0; void *pend_out = nullptr;
 };
@@ -893,7 +930,7 @@ static void zi_free(zamd_engine *e)
 {
     ZiState *z = e->inf;
     if (!z) return;
-    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res); hipFree(z->d_flist); hipFree(z->d_scan);
+    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res); hipFree(z->d_flist); hipFree(z->d_scan); hipFree(z->d_bmarks);
     delete z; e->inf = nullptr;
 }
 
@@ -930,7 +967,8 @@ static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems, bool r
 /* decode (+ resolve when d_out != NULL) the segments already in z->d_segs */
 static int zi_finish(zamd_engine *e, const void *d_head);
 static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint64_t nseg, uint32_t chunk_size,
-                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg, bool regular_tails, bool defer = false, uint32_t parts = 1)
+                  const void *d_head, void *d_out, uint64_t out_bytes, int64_t *bad_seg, bool regular_tails, bool defer = false, uint32_t parts = 1,
+                  uint64_t *bmarks = nullptr, uint32_t mark_step = 0)
 {
     ZiState *z = e->inf;
     hipStream_t s = e->st[0];
@@ -938,8 +976,10 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
     e->n_tm = 0;
     HIPCHK(hipMemsetAsync(z->d_res, 0xff, 8, s));
     tm_begin(e, s, 7, &slot);
-    if (d_out) hipLaunchKernelGGL((k_inf_decode<true>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, z->d_stage);
-    else hipLaunchKernelGGL((k_inf_decode<false>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, (uint16_t *)nullptr);
+    if (d_out) hipLaunchKernelGGL((k_inf_decode<true>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, z->d_stage,
+                                  (uint64_t *)nullptr, 0u);
+    else hipLaunchKernelGGL((k_inf_decode<false>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, (uint16_t *)nullptr,
+                            bmarks, mark_step);
     tm_end(e, s, slot);
     hipLaunchKernelGGL(k_inf_status, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, z->d_res);
     unsigned long long bad = ~0ull;
@@ -1196,15 +1236,36 @@ extern "C" int zamd_inflate_segments_dev(zamd_engine *e, const void *d_comp, uin
     HIPCHK(hipSetDevice(e->device));
     int rc = zi_ensure(e, nseg, need, d_out != nullptr);
     if (rc) return rc;
+    /* a request for block marks holds for this call only, and only a counting pass serves it */
+    ZiState *const z = e->inf;
+    unsigned long long *const h_bmarks = d_out ? nullptr : z->h_bmarks;
+    const uint32_t mark_step = z->bmark_step;
+    z->h_bmarks = nullptr; z->bmark_step = 0;
+    if (h_bmarks && z->bmarks_cap < nseg) {
+        hipFree(z->d_bmarks); z->d_bmarks = nullptr; z->bmarks_cap = 0;
+        const uint64_t want = nseg + nseg / 4 + 16;
+        if (hipMalloc((void **)&z->d_bmarks, want * (ZI_MARKS + 1u) * 8u) != hipSuccess) return ZAMD_MEM_ERROR;
+        z->bmarks_cap = want;
+    }
     HIPCHK(hipMemcpy(e->inf->d_segs, segs, nseg * sizeof(ZiSeg), hipMemcpyHostToDevice));
     /* every segment is reported, so a failing one is not an error of the call */
     int64_t bad = -1;
     bool regular = segs[0].out_off == 0;   /* and the segments back to back, their lengths known beforehand */
     for (uint64_t i = 0; i + 1 < nseg && regular; i++)
         regular = segs[i].out_off + segs[i].out_cap == segs[i + 1].out_off && (segs[i].mode & ZAMD_INF_EXACT);
-    rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad, regular);
+    rc = zi_run(e, d_comp, comp_bytes, nseg, 0, d_head_window, d_out, need, &bad, regular, false, 1, h_bmarks ? z->d_bmarks : nullptr, mark_step);
     if (rc != ZAMD_OK && rc != ZAMD_DATA_ERROR) return rc;
     HIPCHK(hipMemcpy(segs, e->inf->d_segs, nseg * sizeof(ZiSeg), hipMemcpyDeviceToHost));
+    if (h_bmarks) HIPCHK(hipMemcpy(h_bmarks, z->d_bmarks, nseg * (ZI_MARKS + 1u) * 8u, hipMemcpyDeviceToHost));
+    return ZAMD_OK;
+}
+
+extern "C" int zamd_inflate_block_marks(zamd_engine *e, unsigned long long *h_marks, uint32_t step_bytes)
+{
+    static_assert(ZAMD_INF_MARKS == ZI_MARKS + 1u, "a row of block marks has one entry more than a segment can report");
+    if (!e || (h_marks && step_bytes == 0)) return ZAMD_STREAM_ERROR;
+    if (!e->inf) { e->inf = new (std::nothrow) ZiState(); if (!e->inf) return ZAMD_MEM_ERROR; }
+    e->inf->h_bmarks = h_marks; e->inf->bmark_step = h_marks ? step_bytes : 0u;
     return ZAMD_OK;
 }
 

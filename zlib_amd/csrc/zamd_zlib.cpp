@@ -1268,6 +1268,9 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     bool hinted = false;
     size_t hints_used = 0;
     std::vector<uint32_t> chunk_end;        // hinted: chain[chunk_end[k] - 1] is the last segment of the k-th chunk taken
+    std::vector<unsigned long long> marks;  // not hinted: block marks of the counting pass, a row per segment, and the segments' first bits
+    std::vector<uint64_t> mark_bits;
+    bool cut = false;                       // some segment of the chain was cut at its marks
     if (s->hint_pos < s->hints.size() && s->bit_off == 0) {
         uint64_t pos = 0;
         const unsigned per = s->hint_splits.size() == s->hints.size() / 2 * s->hint_per ? s->hint_per : 0u;
@@ -1390,6 +1393,15 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
             }
         }
 
+        // the counting pass notes block boundaries inside its segments (one about every MARK_STEP bytes of output): the pass
+        // that writes the output cuts the segments there, a wavefront to a part (a 1 MiB chunk is some 50 ms of one
+        // wavefront's time)
+        static const uint32_t MARK_STEP = (uint32_t)env_u64("ZAMD_Z_INF_MARK_KIB", 128) << 10;
+        if (MARK_STEP) {
+            marks.assign(segs.size() * ZAMD_INF_MARKS, 0ull);
+            for (const zamd_inflate_seg &g : segs) mark_bits.push_back(g.in_bit);
+            if (zamd_inflate_block_marks(e, marks.data(), MARK_STEP) != 0) return Z_MEM_ERROR;
+        }
         if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, segs.data(), segs.size(), nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
 
         tr.lap("count");
@@ -1427,18 +1439,38 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         size_t idx = 0;
         for (;;) {
             zamd_inflate_seg g = segs[idx];
+            bool prefix = false;
             if (g.out_len > out_batch && g.out_len > 0 && chain.empty()) {
                 // one segment larger than the output batch: take a whole-block prefix of it
                 zamd_inflate_seg one = g; one.out_cap = out_batch; one.status = 0;
                 if (zamd_inflate_segments_dev(e, g_gpu.d_in, in_n, &one, 1, nullptr, nullptr, 0) != 0) return Z_MEM_ERROR;
                 if (one.out_len == 0) { strm->msg = "deflate block too large for the GPU engine"; s->mode = IM_MEM; return Z_MEM_ERROR; }
-                g = one; g.status = 3;
+                g = one; g.status = 3; prefix = true;
             }
-            if ((produced + g.out_len > out_batch || chain.size() >= 32768) && !chain.empty()) break;
+            if ((produced + g.out_len > out_batch || chain.size() + ZAMD_INF_MARKS > 32768) && !chain.empty()) break;
             if (g.end_bit > g.in_bit || g.status == 1) {
-                g.win_avail = (uint32_t)((s->hist.size() + produced) < HIST ? (s->hist.size() + produced) : HIST);
-                g.out_off = produced; g.out_cap = g.out_len; g.in_end_bit = g.end_bit; g.mode = ZAMD_INF_EXACT;
-                chain.push_back(g);
+                // the segment's block marks cut it into parts; marks that are out of order or outside the segment end the list
+                const unsigned long long *row = nullptr;
+                if (!prefix && !mark_bits.empty()) {
+                    const size_t r = (size_t)(std::lower_bound(mark_bits.begin(), mark_bits.end(), g.in_bit) - mark_bits.begin());
+                    if (r < mark_bits.size() && mark_bits[r] == g.in_bit) row = &marks[r * ZAMD_INF_MARKS];
+                }
+                uint64_t pbit = g.in_bit, pout = 0;
+                auto part = [&](uint64_t bit_end, uint64_t out_end, uint32_t status) {
+                    zamd_inflate_seg q = g;
+                    q.in_bit = pbit; q.in_end_bit = q.end_bit = bit_end; q.out_off = produced + pout; q.out_cap = q.out_len = out_end - pout;
+                    q.win_avail = (uint32_t)((s->hist.size() + q.out_off) < HIST ? (s->hist.size() + q.out_off) : HIST);
+                    q.mode = ZAMD_INF_EXACT; q.status = status;
+                    chain.push_back(q);
+                    pbit = bit_end; pout = out_end;
+                };
+                for (unsigned k = 0; row && k < ZAMD_INF_MARKS; k++) {
+                    const uint64_t bit = g.in_bit + (row[k] >> 32), off = row[k] & 0xffffffffull;
+                    if (row[k] == 0 || off <= pout || off >= g.out_len || bit <= pbit || bit >= g.end_bit) break;
+                    part(bit, off, 0);
+                    cut = true;
+                }
+                part(g.end_bit, g.out_len, g.status);
                 produced += g.out_len; end_bit = g.end_bit;
             }
             if (g.status >= 16) {
@@ -1461,11 +1493,12 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     if (!hinted) { drop_hints(s); }      // progress off the chunk grid: an index no longer applies
     tr.lap("chain");
 
-    // Large rounds of indexed chunks that come with split points and can go straight into the caller's buffer are placed in
-    // groups whose transfers overlap the next group's kernels (place_piped), their input uploaded group by group as well.
+    // Large rounds whose segments are cut into parts (indexed chunks that come with split points, counted segments with their
+    // block marks) and can go straight into the caller's buffer are placed in groups whose transfers overlap the next group's
+    // kernels (place_piped); the input of indexed chunks is uploaded group by group as well.
     // (A group's kernels take as long as its slowest segment: whole chunks, at some 60 ms each, make groups a loss.)
     static const uint64_t group_out = env_u64("ZAMD_Z_INF_GROUP_MIB", 512) << 20;
-    const bool piped = hinted && s->hint_per && produced >= 2 * group_out && chain.size() >= 2 && s->out.size() == s->out_pos && strm->avail_out >= produced &&
+    const bool piped = (hinted ? s->hint_per != 0 : cut) && produced >= 2 * group_out && chain.size() >= 2 && s->out.size() == s->out_pos && strm->avail_out >= produced &&
                        group_out >= HIST && !getenv("ZAMD_Z_NO_PIPELINE");
     if (produced && piped) {
         size_t good = 0; uint32_t bad = 0;
