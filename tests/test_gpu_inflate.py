@@ -203,6 +203,60 @@ def test_counting_pass_reports_block_marks(engine, n, step):
     assert "marks" not in res3[0] and [r["out_len"] for r in res3] == [half, n - half]
 
 
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_literal_pairs_always_and_never(mode):
+    """The speculative decode takes two literals in a row as one token where a segment's tokens are short (the other
+    tests run that way).  ZAMD_INF_PAIRS=1 does it everywhere, 0 nowhere (read once per process, hence the child
+    process): the same bytes, the same lengths and block boundaries, the same messages for the reference's bad streams."""
+    import subprocess, sys
+    code = r"""
+import json, os, sys, zlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import _oracle as O, zlib_amd
+eng = zlib_amd.Engine(0)
+for kind in range(5):
+    for level, strategy, chunk, parts in ((6, 0, 1 << 20, 1), (1, 0, 65536, 4), (9, 0, 262144, 4), (6, 2, 262144, 4), (6, 3, 262144, 1), (0, 0, 65536, 1)):
+        n = 1500000 + 777 * kind
+        data = O.corpus(n, kind, 50 + kind)
+        if parts > 1:
+            stream, offs, splits = eng.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk, parts=parts)
+            assert eng.inflate_chunks(stream, offs, n, chunk_size=chunk, splits=splits, parts=parts) == data, (kind, level, strategy)
+        else:
+            stream, offs = eng.deflate_chunks(data, level=level, strategy=strategy, chunk_size=chunk)
+        assert eng.inflate_chunks(stream, offs, n, chunk_size=chunk) == data, (kind, level, strategy)
+one = lambda comp, **kw: dict(dict(in_bit=0, in_end_bit=8 * len(comp), out_off=0, out_cap=1 << 22, win_avail=0, mode=0), **kw)
+for v in json.load(open(os.path.join(%r, "tests", "golden", "inflate_vectors.json")))["raw"]:
+    comp = bytes.fromhex(v["hex"].replace(" ", ""))
+    rc, want, used, msg = O.inflate_raw(comp, b"", 1 << 20)
+    r = eng.inflate_segments(comp, [one(comp)])[0][0]
+    if v["msg"] is None:
+        assert r["status"] == 1 and r["out_len"] == len(want)
+        res, out = eng.inflate_segments(comp, [one(comp, out_cap=len(want))], out_bytes=max(16, len(want)))
+        assert out[:len(want)] == want
+    else:
+        assert r["status"] >= 16 and r["msg"] == v["msg"], (v, r)
+# fixed-code blocks, short codes in rows, input that ends inside a block
+for data in (bytes(range(256)) * 40, b"ab" * 30000 + bytes([7, 7, 9]) * 5000, O.corpus(400000, 2, 2)):
+    for lvl, strat in ((6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, 0)):
+        c = zlib.compressobj(lvl, zlib.DEFLATED, -15, 8, strat)
+        comp = c.compress(data) + c.flush()
+        r = eng.inflate_segments(comp, [one(comp)])[0][0]
+        assert r["status"] == 1 and r["out_len"] == len(data) and (r["end_bit"] + 7) // 8 == len(comp)
+        res, out = eng.inflate_segments(comp, [one(comp, out_cap=len(data))], out_bytes=len(data))
+        assert out == data
+        cut = len(comp) * 2 // 3
+        r = eng.inflate_segments(comp[:cut], [one(comp[:cut])])[0][0]
+        assert r["status"] == 3 and r["end_bit"] <= 8 * cut
+        if r["out_len"]:
+            res, out = eng.inflate_segments(comp[:cut], [one(comp[:cut], out_cap=r["out_len"], in_end_bit=r["end_bit"])], out_bytes=r["out_len"])
+            assert res[0]["status"] == 0 and out == data[:r["out_len"]]
+print("ok")
+""" % (os.path.join(ROOT, "tests"), ROOT, ROOT)
+    env = dict(os.environ, ZAMD_INF_PAIRS=mode)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 def test_truncated_input_reports_last_complete_block(engine):
     data = O.corpus(400000, 0, 2)
     c = zlib.compressobj(6, zlib.DEFLATED, -15)

@@ -213,10 +213,11 @@ __device__ __forceinline__ uint32_t zi_scan_incl(uint32_t v)
  * tlen = its length in bits (bits 0-7) with a note in bits 8+ (1 = end of block,
  * 2 = leave it to the one-token-at-a-time path: long code or invalid symbol),
  * word = the parked-symbol word.  Only lanes on the true token chain matter. */
+#define ZI_W_PAIR    0x40000000u     /* parked-symbol word of two literals: first byte in bits 0-7, second in bits 8-15 */
 #define ZI_SP_EOB    1u
 #define ZI_SP_SCALAR 2u
 __device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, const uint32_t *lut_l, const uint32_t *lut_d,
-                                        uint32_t &tlen, uint32_t &word)
+                                        uint32_t &tlen, uint32_t &word, bool pairs)
 {
     b.bitpos = sb;
     (void)zi_peek(b, lane);                              /* brings the window up to sb */
@@ -251,6 +252,13 @@ __device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, c
     const bool scalar = l1 == 0 || k1 == ZI_K_BAD || (islen && (l2 == 0 || k2 == ZI_K_BAD));
     tlen = islen ? o3 + dx : l1;
     word = islen ? (0x80000000u | ((mlen - 3u) << 16) | dist) : v1;
+    if (pairs) {
+        /* a literal followed by a literal is one token of two bytes: the chain of tokens, which is followed one at a
+         * time, gets shorter where literals come in rows (wave-uniform choice: the second look-up costs every lane) */
+        const uint32_t eb = lut_l[(lo >> l1) & ((1u << ZI_ROOT_L) - 1u)];
+        const uint32_t lb = eb & 15u;
+        if (k1 == ZI_K_LIT && l1 != 0 && lb != 0 && ((eb >> 8) & 3u) == ZI_K_LIT) { tlen = l1 + lb; word = ZI_W_PAIR | ((eb >> 16) << 8) | v1; }
+    }
     if (k1 == ZI_K_EOB) tlen |= ZI_SP_EOB << 8;
     if (scalar) tlen = ZI_SP_SCALAR << 8;
 }
@@ -346,7 +354,7 @@ template <bool WRITE>
 #define ZI_WAVES_PER_SIMD 6
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER_SIMD, ZI_WAVES_PER_SIMD))) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16,
-                                                                                                                                 uint64_t *bmarks, uint32_t mark_step)
+                                                                                                                                 uint64_t *bmarks, uint32_t mark_step, uint32_t pair_mode)
 {
     __shared__ ZiLds L;
     const uint32_t lane = threadIdx.x;
@@ -374,6 +382,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
     uint32_t status = 0xffffffffu, final_seen = 0;
     bool fixed_ready = false;
     uint32_t mysym = 0, k = 0;
+    bool pairs = pair_mode == 1u;
+    uint32_t flushed_bit = (uint32_t)S.in_bit;       /* where the last flush stood in the input (low bits) */
 
     /* flushes the parked symbols; returns false on error (status set) */
     auto flush = [&]() -> bool {
@@ -382,7 +392,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
         const bool valid = lane < k;
         const uint32_t w = mysym;
         const bool ism = valid && (w >> 31);
-        const uint32_t len = valid ? (ism ? ((w >> 16) & 0xffu) + 3u : 1u) : 0u;
+        const bool isp = valid && (w >> 30) == 1u;
+        const uint32_t len = valid ? (ism ? ((w >> 16) & 0xffu) + 3u : isp ? 2u : 1u) : 0u;
+        if (pair_mode == 2u) {
+            /* literal pairs pay where tokens are short (many to a span of 64 bits: following them one at a time is then most
+             * of the work) and cost where they are long (the second look-up of every lane): on below 8 bits a token on
+             * average, off again from 14 (a pair counts as one token of twice the bits) */
+            const uint32_t db = (uint32_t)B.bitpos - flushed_bit;
+            flushed_bit = (uint32_t)B.bitpos;
+            if (k >= 32u) pairs = db < k * (pairs ? 18u : 10u);
+        }
         const uint32_t incl = zi_scan_incl(len);
         const uint32_t off = incl - len;
         const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
@@ -407,7 +426,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
                 const int64_t bs = (int64_t)(pos + base_off);          /* position of stage[0] in the segment */
                 const int32_t sr = (int32_t)o - (int32_t)(w & 0xffffu);
                 uint32_t rem = (in && ism) ? len : 0u, j = 0;
-                if (in && !ism) L.stage[o] = (uint16_t)w;
+                if (in && !ism) { L.stage[o] = (uint16_t)(w & 0xffu); if (isp) L.stage[o + 1u] = (uint16_t)((w >> 8) & 0xffu); }
                 /* long or self-overlapping copies are done by all lanes together, each when
                  * it is the lowest unfinished token (everything below it is complete then) */
                 const bool mycoop = rem != 0 && ((w & 0xffffu) < len || len > 32u);
@@ -568,7 +587,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
             uint32_t sp = 0;                      /* offset of the next token inside the span */
             while (!eob && !bad) {
                 uint32_t tl, wd;
-                zi_span(B, sb, lane, L.lut_l, L.lut_d, tl, wd);
+                zi_span(B, sb, lane, L.lut_l, L.lut_d, tl, wd, pairs);
                 bool restart = false;
                 for (;;) {
                     /* the hot part: nothing but ordinary tokens.  The scalar loop only follows the token
@@ -975,11 +994,13 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
     int slot;
     e->n_tm = 0;
     HIPCHK(hipMemsetAsync(z->d_res, 0xff, 8, s));
+    /* literal pairs in the speculative decode: 0 never, 1 always, 2 where a segment's tokens are mostly literals (tests and measurements set it) */
+    static const uint32_t pair_mode = getenv("ZAMD_INF_PAIRS") ? (uint32_t)atoi(getenv("ZAMD_INF_PAIRS")) : 2u;
     tm_begin(e, s, 7, &slot);
     if (d_out) hipLaunchKernelGGL((k_inf_decode<true>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, z->d_stage,
-                                  (uint64_t *)nullptr, 0u);
+                                  (uint64_t *)nullptr, 0u, pair_mode);
     else hipLaunchKernelGGL((k_inf_decode<false>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, (uint16_t *)nullptr,
-                            bmarks, mark_step);
+                            bmarks, mark_step, pair_mode);
     tm_end(e, s, slot);
     hipLaunchKernelGGL(k_inf_status, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, z->d_res);
     unsigned long long bad = ~0ull;
