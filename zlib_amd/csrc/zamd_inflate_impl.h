@@ -588,6 +588,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
             while (!eob && !bad) {
                 uint32_t tl, wd;
                 zi_span(B, sb, lane, L.lut_l, L.lut_d, tl, wd, pairs);
+                const uint32_t to = tl >= 256u ? 256u + lane : lane + tl;
                 bool restart = false;
                 for (;;) {
                     /* the hot part: nothing but ordinary tokens.  The scalar loop only follows the token
@@ -596,14 +597,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
                      * to the slot of its rank among the starting lanes) */
                     uint32_t t = 0;
                     if (sp < 64) {
+                        /* every lane knows where the token behind its own would start (`to`), so a step of the walk is one
+                         * v_readlane and one comparison; a token that is not an ordinary one points beyond 255 and ends the
+                         * walk standing on it */
                         unsigned long long M = 0;
                         uint32_t s2 = sp;
                         do {
-                            t = __builtin_amdgcn_readlane(tl, s2);
-                            if (t >= 256u) break;
                             M |= 1ull << s2;
-                            s2 += t;
+                            s2 = __builtin_amdgcn_readlane(to, s2);
                         } while (s2 < 64u);
+                        if (s2 >= 256u) { s2 -= 256u; M &= ~(1ull << s2); t = __builtin_amdgcn_readlane(tl, s2); }
                         const uint32_t c = (uint32_t)__popcll(M);
                         if (c) {
                             if (k + c > 64u) { B.bitpos = sb + sp; if (!flush()) { bad = true; break; } }   /* makes room: k = 0 */
