@@ -93,24 +93,26 @@ struct ZiSeg {
  * bits, 8-9 kind, 16-31 value.  Literal/length code: kind 0 literal (value =
  * byte), 1 length (value = base length), 2 end of block, 3 invalid symbol.
  * Distance code: kind 0 (value = base distance) or 3.  Code-length code: value =
- * symbol. */
+ * symbol.  Bits 10 and 11: ZI_E_ODD, ZI_E_EOB. */
 #define ZI_K_LIT 0u
 #define ZI_K_LEN 1u
 #define ZI_K_EOB 2u
 #define ZI_K_BAD 3u
 enum { ZI_T_C = 0, ZI_T_L = 1, ZI_T_D = 2 };
+#define ZI_E_ODD 0x400u      /* entry of a first-level table that the speculative decode leaves to the one-token path: no code this short, or an invalid symbol */
+#define ZI_E_EOB 0x800u      /* the end-of-block code */
 
 __device__ __forceinline__ uint32_t zi_entry(uint32_t table, uint32_t sym, uint32_t len)
 {
     if (table == ZI_T_L) {
         if (sym < 256) return len | (ZI_K_LIT << 8) | (sym << 16);
-        if (sym == 256) return len | (ZI_K_EOB << 8);
-        if (sym > 285) return len | (ZI_K_BAD << 8);
+        if (sym == 256) return len | (ZI_K_EOB << 8) | ZI_E_EOB;
+        if (sym > 285) return len | (ZI_K_BAD << 8) | ZI_E_ODD;
         const uint32_t lc = sym - 257u;
         return len | (zc_len_extra(lc) << 4) | (ZI_K_LEN << 8) | ((zc_len_base(lc) + 3u) << 16);
     }
     if (table == ZI_T_D) {
-        if (sym >= 30) return len | (ZI_K_BAD << 8);
+        if (sym >= 30) return len | (ZI_K_BAD << 8) | ZI_E_ODD;
         return len | (zc_dist_extra(sym) << 4) | ((zc_dist_base(sym) + 1u) << 16);
     }
     return len | (sym << 16);
@@ -131,7 +133,8 @@ struct ZiLds {
     uint8_t cl[20 + 4];
     uint16_t stage[ZI_STAGE];      /* output of the tokens being written, before it goes to memory */
 #ifdef ZI_SPAN_LDS
-    uint32_t ring[128];            /* the 512 input bytes the two window registers hold, where zi_span's lanes pick their own dwords */
+    uint32_t ring[128 + 2];        /* the 512 input bytes the two window registers hold, where zi_span's lanes pick their own dwords
+                                    * (the first two once more behind the end: three dwords in a row never wrap) */
 #endif
     /* block marks of a counting pass (zi_mark): the records, how many, the spacing and the output position the next one waits for */
     uint64_t bm[ZI_MARKS + 1];
@@ -151,6 +154,11 @@ struct ZiBits {
 
 __device__ __forceinline__ uint32_t zi_ldw(const ZiBits &b, uint64_t i) { return i < b.ndw ? b.base[i] : 0u; }
 
+#ifdef ZI_SPAN_LDS
+struct ZiBits;
+__device__ __forceinline__ void zi_ring_put(ZiBits &b, uint32_t lane);
+#endif
+
 __device__ __forceinline__ void zi_bits_init(ZiBits &b, const uint32_t *base, uint64_t ndw, uint64_t bitpos, uint32_t lane)
 {
     b.base = base; b.ndw = ndw; b.bitpos = bitpos;
@@ -158,9 +166,18 @@ __device__ __forceinline__ void zi_bits_init(ZiBits &b, const uint32_t *base, ui
     b.cur = zi_ldw(b, b.wbase + lane);
     b.nxt = zi_ldw(b, b.wbase + 64 + lane);
 #ifdef ZI_SPAN_LDS
-    b.ring[((uint32_t)b.wbase + lane) & 127u] = b.cur; b.ring[((uint32_t)b.wbase + 64u + lane) & 127u] = b.nxt;
+    zi_ring_put(b, lane);
 #endif
 }
+
+#ifdef ZI_SPAN_LDS
+__device__ __forceinline__ void zi_ring_put(ZiBits &b, uint32_t lane)
+{
+    const uint32_t i0 = ((uint32_t)b.wbase + lane) & 127u, i1 = i0 ^ 64u;       /* wbase is a multiple of 64 */
+    b.ring[i0] = b.cur; b.ring[i1] = b.nxt;
+    if (lane < 2u) b.ring[128u + lane] = i0 < 2u ? b.cur : b.nxt;
+}
+#endif
 
 /* >= 33 valid bits at the current position (wave-uniform result) */
 __device__ __forceinline__ uint64_t zi_peek(ZiBits &b, uint32_t lane)
@@ -174,7 +191,7 @@ __device__ __forceinline__ uint64_t zi_peek(ZiBits &b, uint32_t lane)
             dw = (b.bitpos >> 5) - b.wbase;
         }
 #ifdef ZI_SPAN_LDS
-        b.ring[((uint32_t)b.wbase + lane) & 127u] = b.cur; b.ring[((uint32_t)b.wbase + 64u + lane) & 127u] = b.nxt;
+        zi_ring_put(b, lane);
 #endif
     }
     uint32_t d0 = (uint32_t)dw;
@@ -224,7 +241,8 @@ __device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, c
 #ifdef ZI_SPAN_LDS
     const uint32_t t = ((uint32_t)sb & 31u) + lane, kk = t >> 5, sh = t & 31u;
     const uint32_t dwi = (uint32_t)(sb >> 5) + kk;        /* the window holds dwords wbase .. wbase + 127, and sb lies in its first half */
-    const uint32_t A = b.ring[dwi & 127u], Bv = b.ring[(dwi + 1u) & 127u], C = b.ring[(dwi + 2u) & 127u];
+    const uint32_t *const rp = b.ring + (dwi & 127u);
+    const uint32_t A = rp[0], Bv = rp[1], C = rp[2];
 #else
     const uint32_t d0 = (uint32_t)((sb >> 5) - b.wbase);  /* 0..63 */
     uint32_t D[5];
@@ -245,11 +263,11 @@ __device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, c
     const uint32_t o2 = l1 + lx;
     const uint32_t mlen = v1 + ((lo >> l1) & ((1u << lx) - 1u));
     const uint32_t e2 = lut_d[(lo >> o2) & ((1u << ZI_ROOT_D) - 1u)];
-    const uint32_t l2 = e2 & 15u, dx = (e2 >> 4) & 15u, k2 = (e2 >> 8) & 3u, v2 = e2 >> 16;
+    const uint32_t l2 = e2 & 15u, dx = (e2 >> 4) & 15u, v2 = e2 >> 16;
     const uint32_t o3 = o2 + l2;
     const uint32_t dist = v2 + ((uint32_t)(W >> o3) & ((1u << dx) - 1u));
     const bool islen = k1 == ZI_K_LEN;
-    const bool scalar = l1 == 0 || k1 == ZI_K_BAD || (islen && (l2 == 0 || k2 == ZI_K_BAD));
+    const bool scalar = ((e1 | (islen ? e2 : 0u)) & ZI_E_ODD) != 0u;
     tlen = islen ? o3 + dx : l1;
     word = islen ? (0x80000000u | ((mlen - 3u) << 16) | dist) : v1;
     if (pairs) {
@@ -257,9 +275,9 @@ __device__ __forceinline__ void zi_span(ZiBits &b, uint64_t sb, uint32_t lane, c
          * time, gets shorter where literals come in rows (wave-uniform choice: the second look-up costs every lane) */
         const uint32_t eb = lut_l[(lo >> l1) & ((1u << ZI_ROOT_L) - 1u)];
         const uint32_t lb = eb & 15u;
-        if (k1 == ZI_K_LIT && l1 != 0 && lb != 0 && ((eb >> 8) & 3u) == ZI_K_LIT) { tlen = l1 + lb; word = ZI_W_PAIR | ((eb >> 16) << 8) | v1; }
+        if (((e1 | eb) & 0xf00u) == 0u) {                /* both are literals: kind 0, neither flag */ tlen = l1 + lb; word = ZI_W_PAIR | ((eb >> 16) << 8) | v1; }
     }
-    if (k1 == ZI_K_EOB) tlen |= ZI_SP_EOB << 8;
+    tlen |= (e1 & ZI_E_EOB) >> 3;                        /* ZI_SP_EOB << 8 */
     if (scalar) tlen = ZI_SP_SCALAR << 8;
 }
 
@@ -310,7 +328,7 @@ __device__ uint32_t zi_build(ZiLds &L, const uint8_t *lens, uint32_t n, uint32_t
             uint32_t d = (rev >> (root - l)) - T.first[l];
             if (d < T.cnt[l]) { e = zi_entry(T.table, T.sorted[T.off[l] + d], l); break; }
         }
-        T.lut[i] = e;
+        T.lut[i] = e ? e : (uint32_t)ZI_E_ODD;
     }
     __syncthreads();
     return left > 0 ? 2u : 0u;
