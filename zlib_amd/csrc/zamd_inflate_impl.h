@@ -366,10 +366,11 @@ __device__ __noinline__ void zi_mark(ZiLds &L, uint64_t rel_bit, uint64_t pos, u
 }
 
 template <bool WRITE>
-/* registers, not LDS, set the wavefronts per SIMD: 84 registers allow 5; held to 80 (two spilled values) 6 fit and decode
- * 3 % faster, held to 72 (five spills) 7 fit and it is slower */
+/* five wavefronts to a SIMD: the kernel takes 92 registers and spills nothing.  Six (80 registers, two spilled values; the
+ * LDS has room for no more) were 3 % faster while the walk along the tokens took twelve instructions a token, and are 6 %
+ * slower now (8 GiB mixed: 122.4 against 115.0 ms); four are as fast as five on small calls and slower on large ones */
 #ifndef ZI_WAVES_PER_SIMD
-#define ZI_WAVES_PER_SIMD 6
+#define ZI_WAVES_PER_SIMD 5
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER_SIMD, ZI_WAVES_PER_SIMD))) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16,
                                                                                                                                  uint64_t *bmarks, uint32_t mark_step, uint32_t pair_mode)
