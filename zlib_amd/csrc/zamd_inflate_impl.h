@@ -608,7 +608,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
                 uint32_t tl, wd;
                 zi_span(B, sb, lane, L.lut_l, L.lut_d, tl, wd, pairs);
                 const uint32_t to = tl >= 256u ? 256u + lane : lane + tl;
-                bool restart = false;
                 for (;;) {
                     /* the hot part: nothing but ordinary tokens.  The scalar loop only follows the token
                      * lengths and notes where tokens start; their words then move to the parking lanes
@@ -670,10 +669,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
                     }
                     mysym = zi_writelane(mysym, word, k);
                     if (++k == 64) { if (!flush()) { bad = true; break; } }
-                    sb = B.bitpos; sp = 0; restart = true;
-                    break;
+                    /* the walk goes on behind the token, in this span if the token ends inside it */
+                    sp = (uint32_t)(B.bitpos - sb);
+                    if (sp >= 64u) break;
                 }
-                if (!restart) { sb += 64; sp -= 64; }
+                sb += 64; sp -= 64;
             }
             if (bad) break;
         }
