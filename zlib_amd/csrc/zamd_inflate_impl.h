@@ -131,7 +131,7 @@ struct ZiLds {
     uint32_t cntw[16];
     uint8_t lens[320 + 8];
     uint8_t cl[20 + 4];
-    uint16_t stage[ZI_STAGE];      /* output of the tokens being written, before it goes to memory */
+    __attribute__((aligned(16))) uint16_t stage[ZI_STAGE];      /* output of the tokens being written, before it goes to memory */
 #ifdef ZI_SPAN_LDS
     uint32_t ring[128 + 2];        /* the 512 input bytes the two window registers hold, where zi_span's lanes pick their own dwords
                                     * (the first two once more behind the end: three dwords in a row never wrap) */
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
                 const bool in = valid && lane >= done_tok && (incl - base_off) <= ZI_STAGE;
                 const uint32_t cnt = (uint32_t)__popcll(__ballot(in));
                 const uint32_t sub_total = __builtin_amdgcn_readlane(incl, done_tok + cnt - 1) - base_off;
-                for (uint32_t j = lane; j < sub_total; j += 64) L.stage[j] = (uint16_t)ZI_EMPTY;
+                *(uint4 *)(L.stage + 8u * lane) = make_uint4(~0u, ~0u, ~0u, ~0u);      /* all of it ZI_EMPTY: one store */
                 const uint32_t o = off - base_off;
                 const int64_t bs = (int64_t)(pos + base_off);          /* position of stage[0] in the segment */
                 const int32_t sr = (int32_t)o - (int32_t)(w & 0xffffu);
@@ -470,21 +470,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
                     }
                     if (rem && !mycoop) {
                         const int32_t sidx = sr + (int32_t)j;
-                        if (sidx + 3 < 0) {
+                        if (sidx + 7 < 0) {
+                            /* eight elements whose sources all lie below the sub-batch: one 16-byte load (a trip to memory
+                             * is what an iteration of this loop costs) */
                             const int64_t a = bs + sidx;
-                            uint32_t v[4];
+                            uint32_t v[8];
                             if (a >= 0) {
-                                uint64_t x;
-                                __builtin_memcpy(&x, dst + a, 8);
-                                v[0] = (uint32_t)x & 0xffffu; v[1] = (uint32_t)(x >> 16) & 0xffffu;
-                                v[2] = (uint32_t)(x >> 32) & 0xffffu; v[3] = (uint32_t)(x >> 48);
+                                uint4 x;
+                                __builtin_memcpy(&x, dst + a, 16);
+                                v[0] = x.x & 0xffffu; v[1] = x.x >> 16; v[2] = x.y & 0xffffu; v[3] = x.y >> 16;
+                                v[4] = x.z & 0xffffu; v[5] = x.z >> 16; v[6] = x.w & 0xffffu; v[7] = x.w >> 16;
                             } else {
 #pragma unroll
-                                for (int i = 0; i < 4; i++) v[i] = (a + i < 0) ? (uint32_t)(ZI_MARK + 32768 + (a + i)) : (uint32_t)dst[a + i];
+                                for (int i = 0; i < 8; i++) v[i] = (a + i < 0) ? (uint32_t)(ZI_MARK + 32768 + (a + i)) : (uint32_t)dst[a + i];
                             }
-                            const uint32_t take = rem < 4u ? rem : 4u;
+                            const uint32_t take = rem < 8u ? rem : 8u;
 #pragma unroll
-                            for (uint32_t i = 0; i < 4; i++) if (i < take) L.stage[o + j + i] = (uint16_t)v[i];
+                            for (uint32_t i = 0; i < 8; i++) if (i < take) L.stage[o + j + i] = (uint16_t)v[i];
                             j += take; rem -= take;
                         } else {
                             uint32_t v;
@@ -494,7 +496,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER
                         }
                     }
                 }
-                for (uint32_t jj = lane; jj < sub_total; jj += 64) dst[bs + jj] = L.stage[jj];
+                {
+                    /* eight elements a lane: one 16-byte store where all eight belong to the sub-batch (the addresses are
+                     * 2-byte aligned only), single elements at its end */
+                    const uint32_t j0 = 8u * lane;
+                    if (j0 + 8u <= sub_total) {
+                        const uint4 v = *(const uint4 *)(L.stage + j0);
+                        __builtin_memcpy(dst + bs + j0, &v, 16);
+                    } else {
+                        for (uint32_t jj = j0; jj < sub_total; jj++) dst[bs + jj] = L.stage[jj];
+                    }
+                }
                 __threadfence_block();                                 /* later sub-batches and batches read these */
                 done_tok += cnt; base_off += sub_total;
             }
