@@ -733,9 +733,13 @@ __global__ __launch_bounds__(1024) void k_inf_status(const ZiSeg *segs, uint64_t
     if (best != ~0ull) atomicMin(result, best);
 }
 
+/* Index into the 32 KiB in front of a segment that a window marker stands for.  The decoder writes no element above
+ * ZI_MARK + 32767; the bound keeps every address the resolve step forms inside its buffers whatever the stage holds. */
+__device__ __forceinline__ uint32_t zi_mark_index(uint32_t v) { const uint32_t i = v - ZI_MARK; return i < 32767u ? i : 32767u; }
+
 __device__ __forceinline__ uint8_t zi_window_byte(const ZiSeg &S, uint32_t marker, const uint8_t *out8, const uint8_t *head)
 {
-    int64_t q = (int64_t)S.out_off - 32768 + (int64_t)(marker - ZI_MARK);
+    int64_t q = (int64_t)S.out_off - 32768 + (int64_t)zi_mark_index(marker);
     if (q >= 0) return __hip_atomic_load(out8 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return head[32768 + q];
 }
@@ -760,7 +764,7 @@ __global__ __launch_bounds__(1024) void k_inf_tail_pre(const ZiSeg *segs, const 
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&marks[si], (uint32_t)__popcll(b));
         base = __builtin_amdgcn_readfirstlane(base);
-        if (mk) mlist[(uint64_t)si * 32768u + base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)e | ((v - ZI_MARK) << 16);
+        if (mk) mlist[(uint64_t)si * 32768u + base + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)e | (zi_mark_index(v) << 16);
     }
 }
 
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(1024) void k_inf_ref_init(const ZiSeg *segs, const 
         else {
             /* the byte lies less than 32 KiB in front of this segment, so inside the last 32 KiB of whichever segment holds it
              * (segments are back to back; short and empty ones are stepped over) or in the window in front of them all */
-            const int64_t q = (int64_t)S.out_off - 32768 + (int64_t)(v - ZI_MARK);
+            const int64_t q = (int64_t)S.out_off - 32768 + (int64_t)zi_mark_index(v);
             int64_t sj = (int64_t)si - 1;
             while (sj >= 0 && (int64_t)segs[sj].out_off > q) sj--;
             if (sj < 0) r = head ? (ZI_REF_BYTE | head[32768 + q]) : (ZI_REF_HEAD | (uint32_t)(32768 + q));
