@@ -946,3 +946,29 @@ print("ok")
     env = dict(os.environ, ZAMD_Z_INF_GROUP_MIB="16")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("wbits,first_flush", [(31, None), (15, Z.Z_SYNC_FLUSH), (-15, Z.Z_FULL_FLUSH), (-15, Z.Z_PARTIAL_FLUSH)])
+def test_input_of_whole_batches_ends_like_any_other(monkeypatch, wbits, first_flush):
+    """Input that is exactly so many engine batches long: the flush belongs to the last batch that has input (the final
+    block holds data, a sync flush writes one marker), so the stream does not depend on the batch size (deflate.c:873-945
+    knows no batches).  Overlapped, batch by batch and with a small output buffer."""
+    import zlib as pyz
+    monkeypatch.setenv("ZAMD_Z_CHUNK", "262144")
+    data = bytes(zlib_amd.corpus(5 << 20, 4, 12))
+    cut = 2 << 20
+    flushes = {cut: first_flush} if first_flush is not None else None
+    big = len(data) + (len(data) >> 3) + (1 << 16)
+    monkeypatch.setenv("ZAMD_Z_BATCH_MIB", "16")
+    want, tot_w = Z.deflate_stream(data, 6, wbits, out_step=big, flushes=flushes)          # every call is one batch
+    for batch in ("1", "5"):
+        monkeypatch.setenv("ZAMD_Z_BATCH_MIB", batch)
+        piped, tot_p = Z.deflate_stream(data, 6, wbits, out_step=big, flushes=flushes)
+        monkeypatch.setenv("ZAMD_Z_NO_PIPELINE", "1")
+        plain, tot_q = Z.deflate_stream(data, 6, wbits, out_step=big, flushes=flushes)
+        monkeypatch.delenv("ZAMD_Z_NO_PIPELINE")
+        small, tot_s = Z.deflate_stream(data, 6, wbits, out_step=70000, flushes=flushes)
+        fed, tot_f = Z.deflate_stream(data, 6, wbits, out_step=big, flushes=flushes, in_step=(1 << 20) - 4096)
+        assert piped == want and plain == want and small == want and fed == want, (batch, len(piped), len(plain), len(small), len(fed), len(want))
+        assert tot_p == tot_w and tot_q == tot_w and tot_s == tot_w and tot_f == tot_w
+    assert pyz.decompressobj(wbits).decompress(want) == data

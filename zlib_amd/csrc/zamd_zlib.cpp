@@ -195,6 +195,7 @@ enum { ST_INIT = 42, ST_BUSY = 113, ST_FINISH = 666 };   // deflate.h:51-57 valu
 struct DState {
     uint32_t magic;
     int status, wrap, level, strategy, mem_level, w_bits, last_flush;
+    int flush_done = -1;     // the flush whose blocks are written but whose output the caller is still collecting (-1: none)
     uint32_t chunk_size;
     uint64_t batch_bytes;
     gz_headerp gzhead;
@@ -673,6 +674,7 @@ int deflateResetKeep(z_streamp strm) {
     s->status = s->wrap ? ST_INIT : ST_BUSY;
     strm->adler = s->wrap == 2 ? 0 : 1;
     s->last_flush = Z_NO_FLUSH;
+    s->flush_done = -1;
     s->trailer_done = false;
     s->have_dict = false; s->dictid = 0;
     s->prime_bits = 0; s->prime_val = 0;
@@ -810,12 +812,17 @@ static int deflate_body(z_streamp strm, int flush) {
     if (strm->avail_out == 0) { strm->msg = err_msg(Z_BUF_ERROR); return Z_BUF_ERROR; }
     int old_flush = s->last_flush;
     s->last_flush = flush;
+    // A flush is complete when deflate() returns with room left in the output (zlib.h:277-282).  Its blocks are written by
+    // one engine call, however long the caller takes to collect them: calls that only collect must not flush again
+    // (the reference writes the marker once the block in front of it has gone out, deflate.c:904-945).
+    const bool collecting = s->flush_done == flush && strm->avail_in == 0 && flush != Z_NO_FLUSH;
+    s->flush_done = -1;
 
     if (s->status == ST_INIT) write_header(strm, s);
 
     if (s->out.size() != s->out_pos) {                   // deflate.c:869-881
         flush_pending(strm, s);
-        if (strm->avail_out == 0) { s->last_flush = -1; return Z_OK; }
+        if (strm->avail_out == 0) { s->last_flush = -1; if (collecting) s->flush_done = flush; return Z_OK; }
     } else if (strm->avail_in == 0 && rank_of(flush) <= rank_of(old_flush) && flush != Z_FINISH) {
         strm->msg = err_msg(Z_BUF_ERROR);                // deflate.c:887-890
         return Z_BUF_ERROR;
@@ -841,7 +848,11 @@ static int deflate_body(z_streamp strm, int flush) {
         int rc;
         // whole batches that can go straight from the caller's input to the caller's output, overlapped on the GPU
         uint64_t full = s->in.empty() ? strm->avail_in / s->batch_bytes : 0;
-        bool with_last = flush != Z_NO_FLUSH && s->status != ST_FINISH;
+        const bool flushing = flush != Z_NO_FLUSH && s->status != ST_FINISH;
+        bool with_last = flushing;
+        // the flush belongs to the last batch that has input: input of exactly so many batches must not leave it an empty
+        // one (that would be a block, or a marker, which deflate() with all the input at once does not write)
+        if (flushing && full && strm->avail_in % s->batch_bytes == 0) full--;
         if (full >= 1) {
             const uint64_t per = zamd_deflate_bound(s->batch_bytes, s->chunk_size, s->mem_level) + 64;
             const uint64_t fit = (uint64_t)strm->avail_out / per;
@@ -863,15 +874,18 @@ static int deflate_body(z_streamp strm, int flush) {
             if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
             if (with_last) { flushed = true; break; }
         } else if (s->in.empty() && strm->avail_in >= s->batch_bytes) {
-            rc = run_batch(strm, s, strm->next_in, s->batch_bytes, 0);
+            const bool last = flushing && strm->avail_in == s->batch_bytes;       // the flush's own batch
+            const int tail = flush == Z_PARTIAL_FLUSH ? ZAMD_TAIL_ALIGN : flush == Z_BLOCK ? ZAMD_TAIL_NONE : ZAMD_TAIL_SYNC;   // deflate.c:923-945
+            rc = last ? run_batch(strm, s, strm->next_in, s->batch_bytes, flush == Z_FINISH, tail) : run_batch(strm, s, strm->next_in, s->batch_bytes, 0);
             if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
             strm->next_in += s->batch_bytes; strm->avail_in -= (uInt)s->batch_bytes; strm->total_in += s->batch_bytes;
+            if (last) { flushed = true; break; }
         } else {
             uint64_t take = s->batch_bytes - s->in.size();
             if (take > strm->avail_in) take = strm->avail_in;
             s->in.insert(s->in.end(), strm->next_in, strm->next_in + take);
             strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take;
-            if (s->in.size() < s->batch_bytes) break;
+            if (s->in.size() < s->batch_bytes || (flushing && strm->avail_in == 0)) break;     // (a full batch that is the flush's own: finish_batch)
             rc = run_batch(strm, s, s->in.data(), s->in.size(), 0);
             if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
             s->in.clear();
@@ -881,10 +895,12 @@ static int deflate_body(z_streamp strm, int flush) {
     }
 
     if (flush != Z_NO_FLUSH && s->status != ST_FINISH) {
-        int rc = finish_batch(strm, s, flush, flushed);
-        if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
-        flush_pending(strm, s);
-        if (strm->avail_out == 0 && s->out.size() != s->out_pos) { s->last_flush = -1; return Z_OK; }
+        if (!collecting) {
+            int rc = finish_batch(strm, s, flush, flushed);
+            if (rc != Z_OK) { strm->msg = err_msg(rc); return rc; }
+            flush_pending(strm, s);
+        }
+        if (strm->avail_out == 0 && s->out.size() != s->out_pos) { s->last_flush = -1; s->flush_done = flush; return Z_OK; }
     }
     if (flush != Z_FINISH) return Z_OK;
     flush_pending(strm, s);
