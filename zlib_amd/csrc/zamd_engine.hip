@@ -29,6 +29,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
 #include "zamd_core.h"
 #include "../../include/zamd.h"
 
@@ -2619,6 +2623,53 @@ extern "C" int zamd_dev_download(zamd_engine *e, void *h_dst, const void *d_src,
  * measured four to five times slower than alone; this one keeps its pace.  One upload and one download may run at the
  * same time (from two threads), not two of a kind; both directions share one stream, in the order they were queued. */
 #define ZE_STAGE_BYTES (32ull << 20)
+/* The host's side of a staged transfer, several threads to a piece: one thread's memcpy runs at half of what the copy
+ * engine moves (a 3.5 GiB download: 130 ms with one thread).  The helpers live as long as the transfer that made them;
+ * ZAMD_COPY_THREADS (default 4) is the number of threads to a piece, the caller's own included. */
+struct ZeParCopy {
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv_go, cv_done;
+    uint64_t gen = 0; int pending = 0; bool quit = false;
+    uint8_t *dst = nullptr; const uint8_t *src = nullptr; uint64_t len = 0, slice = 0;
+    ZeParCopy()
+    {
+        static const int want = [] { const char *v = getenv("ZAMD_COPY_THREADS"); const int k = v ? atoi(v) : 4; return k < 1 ? 1 : k > 16 ? 16 : k; }();
+        try {
+            for (int i = 1; i < want; i++) th.emplace_back([this, i] { work(i); });
+        } catch (...) { /* fewer helpers, or none: the caller copies the rest itself */ }
+    }
+    ~ZeParCopy()
+    {
+        { std::lock_guard<std::mutex> g(mu); quit = true; }
+        cv_go.notify_all();
+        for (std::thread &t : th) t.join();
+    }
+    void part(int i) const
+    {
+        const uint64_t a = (uint64_t)i * slice;
+        if (a < len) memcpy(dst + a, src + a, len - a < slice ? len - a : slice);
+    }
+    void work(int i)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> g(mu); cv_go.wait(g, [&] { return quit || gen != seen; }); if (quit) return; seen = gen; }
+            part(i);
+            { std::lock_guard<std::mutex> g(mu); pending--; }
+            cv_done.notify_one();
+        }
+    }
+    void copy(void *d, const void *s, uint64_t l)
+    {
+        if (th.empty() || l < (4u << 20)) { memcpy(d, s, l); return; }
+        const uint64_t n = th.size() + 1;
+        { std::lock_guard<std::mutex> g(mu); dst = (uint8_t *)d; src = (const uint8_t *)s; len = l; slice = ((l + n - 1) / n + 63) & ~63ull; pending = (int)th.size(); gen++; }
+        cv_go.notify_all();
+        part(0);
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return pending == 0; });
+    }
+};
 static int stage_ready(zamd_engine *e, int dir)
 {
     for (int h = 0; h < 2; h++)
@@ -2634,11 +2685,12 @@ extern "C" int zamd_dev_upload_staged(zamd_engine *e, void *d_dst, const void *h
     for (int h = 0; h < 2; h++) HIPCHK(hipEventCreateWithFlags(&ev[h], hipEventDisableTiming));
     int rc = ZAMD_OK;
     uint64_t piece = 0;
+    ZeParCopy pc;
     for (uint64_t at = 0; at < bytes && rc == ZAMD_OK; at += ZE_STAGE_BYTES, piece++) {
         const int h = (int)(piece & 1);
         const uint64_t len = bytes - at < ZE_STAGE_BYTES ? bytes - at : ZE_STAGE_BYTES;
         if (piece >= 2 && hipEventSynchronize(ev[h]) != hipSuccess) { rc = ZAMD_HIP_ERROR(1); break; }   /* the half is free again */
-        memcpy(e->h_stage[0][h], (const uint8_t *)h_src + at, len);
+        pc.copy(e->h_stage[0][h], (const uint8_t *)h_src + at, len);
         if (hipMemcpyAsync((uint8_t *)d_dst + at, e->h_stage[0][h], len, hipMemcpyHostToDevice, e->st_up) != hipSuccess ||
             hipEventRecord(ev[h], e->st_up) != hipSuccess) rc = ZAMD_HIP_ERROR(1);
     }
@@ -2655,6 +2707,7 @@ extern "C" int zamd_dev_download_staged(zamd_engine *e, void *h_dst, const void 
     for (int h = 0; h < 2; h++) HIPCHK(hipEventCreateWithFlags(&ev[h], hipEventDisableTiming));
     int rc = ZAMD_OK;
     const uint64_t pieces = (bytes + ZE_STAGE_BYTES - 1) / ZE_STAGE_BYTES;
+    ZeParCopy pc;
     /* piece k + 1 is on its way while the host copies piece k out */
     for (uint64_t k = 0; k <= pieces && rc == ZAMD_OK; k++) {
         if (k < pieces) {
@@ -2665,7 +2718,7 @@ extern "C" int zamd_dev_download_staged(zamd_engine *e, void *h_dst, const void 
         if (k >= 1) {
             const uint64_t at = (k - 1) * ZE_STAGE_BYTES, len = bytes - at < ZE_STAGE_BYTES ? bytes - at : ZE_STAGE_BYTES;
             if (hipEventSynchronize(ev[(k - 1) & 1]) != hipSuccess) { rc = ZAMD_HIP_ERROR(1); break; }
-            memcpy((uint8_t *)h_dst + at, e->h_stage[1][(k - 1) & 1], len);
+            pc.copy((uint8_t *)h_dst + at, e->h_stage[1][(k - 1) & 1], len);
         }
     }
     if (hipStreamSynchronize(e->st_down) != hipSuccess) rc = ZAMD_HIP_ERROR(1);

@@ -880,9 +880,11 @@ static int deflate_body(z_streamp strm, int flush) {
         // one (that would be a block, or a marker, which deflate() with all the input at once does not write)
         if (flushing && full && strm->avail_in % s->batch_bytes == 0) full--;
         if (full >= 1) {
-            const uint64_t per = zamd_deflate_bound(s->batch_bytes, s->chunk_size, s->mem_level) + 64;
-            const uint64_t fit = (uint64_t)strm->avail_out / per;
-            if (full + (with_last ? 1 : 0) > fit) { with_last = false; if (full > fit) full = fit; }
+            // room for the bound of what the row takes (the bounds of its engine calls add up to that of their input, and
+            // a few bytes per call)
+            auto need = [&](uint64_t bytes, uint64_t calls) { return zamd_deflate_bound(bytes, s->chunk_size, s->mem_level) + 96 * calls + 64; };
+            if (with_last && strm->avail_out < need(strm->avail_in, full + 1)) with_last = false;
+            if (!with_last) while (full && strm->avail_out < need(full * s->batch_bytes, full)) full--;
         }
         // several devices: the whole row of batches as one call on all of them (flushes that end inside a byte stay on one)
         static const bool multi_on = getenv("ZAMD_DEVICES") != nullptr;
@@ -1539,7 +1541,10 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     // block marks) and can go straight into the caller's buffer are placed in groups whose transfers overlap the next group's
     // kernels (place_piped); the input of indexed chunks is uploaded group by group as well.
     // (A group's kernels take as long as its slowest segment: whole chunks, at some 60 ms each, make groups a loss.)
-    static const uint64_t group_out = env_u64("ZAMD_Z_INF_GROUP_MIB", 512) << 20;
+    // (A group's kernels take some 20 ms at 512 MiB and 27 at 1 GiB, its download 12 ms per 512 MiB: large rounds take large
+    // groups, 3.5 GiB in groups of 512 MiB 139 ms, of 1 GiB 128.)
+    static const uint64_t group_env = env_u64("ZAMD_Z_INF_GROUP_MIB", 0) << 20;
+    const uint64_t group_out = group_env ? group_env : produced >= (3ull << 30) ? (1ull << 30) : (512ull << 20);
     const bool piped = (hinted ? s->hint_per != 0 : cut) && produced >= 2 * group_out && chain.size() >= 2 && s->out.size() == s->out_pos && strm->avail_out >= produced &&
                        group_out >= HIST && !getenv("ZAMD_Z_NO_PIPELINE");
     if (produced && piped) {
