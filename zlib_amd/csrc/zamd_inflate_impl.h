@@ -10,10 +10,13 @@
  *     memory access per symbol (the speculative decode of 64 bit offsets at once
  *     reads a copy of the same 512 bytes in LDS, three dwords per lane);
  *   - Huffman tables are per-wave LDS images: a 2^9 (literal/length) or 2^8
- *     (distance) first-level table of u16 {symbol, length}; longer codes fall
- *     back to the canonical first-code search;
- *   - decoded symbols are parked one per lane; every 64 symbols the wave scans
- *     their lengths, stores the literals and copies the matches cooperatively.
+ *     (distance) first-level table of u32 {code length, extra bits, kind, flags,
+ *     value}; longer codes fall back to the canonical first-code search;
+ *   - every lane decodes the token that would start at its own bit offset of a
+ *     64-bit span and notes where the token behind it would start; the wave walks
+ *     the real tokens through those notes (one v_readlane a token) and parks them
+ *     one per lane; every 64 tokens it scans their lengths, stores the literals
+ *     and copies the matches through a stage in LDS.
  * Output is first written as 16-bit elements: values >= 256 name a byte of the
  * 32 KiB of output in front of the segment, which another wave is producing at
  * the same time.  k_inf_tail_* then resolve the last 32 KiB of every segment in
@@ -25,9 +28,10 @@
  * length sets); error numbers map to the reference's message strings.
  */
 
-/* Table and stage sizes set the LDS per wavefront and with it the wavefronts a CU holds: 10 root bits and a stage of
- * 1 024 elements (9 KB, 17 wavefronts) decode 8 GiB at 52 GB/s, 9 bits and 512 elements (6 KB, 27 wavefronts) at 56;
- * 8 root bits send too many symbols to the search for longer codes (41 GB/s). */
+/* Table and stage sizes set the LDS per wavefront (6.6 KB as they are: room for the 20 wavefronts a CU runs of this
+ * kernel, not for many more).  Measured when the kernel ran 27 wavefronts to a CU: 10 root bits and a stage of 1 024
+ * elements (9 KB, 17 wavefronts) decoded 8 GiB at 52 GB/s, 9 bits and 512 elements at 56; 8 root bits send too many
+ * symbols to the search for longer codes (41 GB/s). */
 #ifndef ZI_ROOT_L
 #define ZI_ROOT_L 9
 #endif
