@@ -48,7 +48,9 @@
 #define ZI_STAGE  512u       /* elements of the per-wave output stage (>= 258) */
 #endif
 #ifndef ZI_SPLIT_SEGMENTS
-#define ZI_SPLIT_SEGMENTS 14336u   /* zamd_inflate_split_dev cuts chunks into parts while that many segments are not exceeded */
+#define ZI_SPLIT_SEGMENTS 20480u   /* zamd_inflate_split_dev cuts chunks into parts while that many segments are not exceeded: four times
+                                    * the 5 120 wavefronts of k_inf_decode that the GPU holds */
+#define ZI_SPLIT_CHUNKS   5120u    /* ... and while the chunks alone do not fill those */
 #endif
 #define ZI_MARKS  15u        /* block boundaries a segment can report (zamd_inflate_block_marks); a row of the result has one more entry */
 #define ZI_EMPTY  0xffffu    /* stage element not produced yet (no byte or marker has this value) */
@@ -1196,10 +1198,12 @@ extern "C" int zamd_inflate_split_dev(zamd_engine *e, const void *d_comp, uint64
     HIPCHK(hipSetDevice(e->device));
     /* How many of the parts to use: segments beyond what fills the GPU a few times over gain nothing in the decode (it
      * runs at the rate the whole GPU decodes at by then) and cost their 32 KiB each in the resolve step.  Measured on 1 MiB
-     * chunks: 8 192 chunks are best left whole, 4 096 cut in three or four, 512 in sixteen. */
+     * chunks: 8 192 chunks are best left whole (in two parts 131 ms against 117, in three 120), 4 096 cut in five (1 to 3 %
+     * better than in three on three corpora; six and more worse again), 512 in sixteen. */
     static const uint64_t seg_limit = getenv("ZAMD_INF_SPLIT_SEGMENTS") ? strtoull(getenv("ZAMD_INF_SPLIT_SEGMENTS"), nullptr, 10) : ZI_SPLIT_SEGMENTS;
     uint32_t use = parts;
     while (use > 1 && n_chunks * use > seg_limit) use--;
+    if (n_chunks > ZI_SPLIT_CHUNKS && !getenv("ZAMD_INF_SPLIT_SEGMENTS")) use = 1;
     if (use < 2) return zamd_inflate_shard_dev(e, d_comp, comp_bytes, d_chunk_off, n_chunks, chunk_size, d_head_window, d_out, n_out, bad_chunk);
     /* the references of the resolve step are 30 bits wide: 32 768 segments to a round, each round on top of the output
      * of the one before it */
