@@ -972,3 +972,10 @@ def test_input_of_whole_batches_ends_like_any_other(monkeypatch, wbits, first_fl
         assert piped == want and plain == want and small == want and fed == want, (batch, len(piped), len(plain), len(small), len(fed), len(want))
         assert tot_p == tot_w and tot_q == tot_w and tot_s == tot_w and tot_f == tot_w
     assert pyz.decompressobj(wbits).decompress(want) == data
+    # sizes at which the row of overlapped engine calls has nothing, or less than a chunk, left for its call before the last
+    for n in ((3 << 20) + 77, (3 << 20), (5 << 20) - 262144 + 5, (3 << 20) + 262144):
+        monkeypatch.setenv("ZAMD_Z_BATCH_MIB", "16")
+        want, tot_w = Z.deflate_stream(data[:n], 6, wbits, out_step=big)
+        monkeypatch.setenv("ZAMD_Z_BATCH_MIB", "1")
+        piped, tot_p = Z.deflate_stream(data[:n], 6, wbits, out_step=big)
+        assert piped == want and tot_p == tot_w, (n, len(piped), len(want))

@@ -462,7 +462,10 @@ int run_batches_piped(z_streamp strm, DState *s, uint64_t full, int last_flush) 
         if (wide && s->level >= 4 && small >= wsize && small >= s->chunk_size && total >= big + 2 * small) {
             sizes.push_back(small); left -= small;
             while (left > big + small) { sizes.push_back(big); left -= big; }
-            if (left > small) { const uint64_t mid = (left - small) / s->chunk_size * s->chunk_size; sizes.push_back(mid); left -= mid; }   // only the row's last call may end inside a chunk
+            if (left > small) {                               // only the row's last call may end inside a chunk
+                const uint64_t mid = (left - small) / s->chunk_size * s->chunk_size;
+                if (mid) { sizes.push_back(mid); left -= mid; }
+            }
             if (left) sizes.push_back(left);
         } else {
             for (uint64_t i = 0; i < full; i++) { sizes.push_back(nb); left -= nb; }
