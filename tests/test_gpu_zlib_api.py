@@ -979,3 +979,12 @@ def test_input_of_whole_batches_ends_like_any_other(monkeypatch, wbits, first_fl
         monkeypatch.setenv("ZAMD_Z_BATCH_MIB", "1")
         piped, tot_p = Z.deflate_stream(data[:n], 6, wbits, out_step=big)
         assert piped == want and tot_p == tot_w, (n, len(piped), len(want))
+
+
+def test_random_calls_of_the_stream_api_agree():
+    """tests/gpu_api_fuzz.py: random batch and chunk sizes, input and output steps and flush points; the stream is the one
+    a single batch gives, Python's zlib inflates it, and so does inflate() with random steps, with and without the index.
+    (A child process: the tool sets the sizes through the environment.)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(Z.ROOT, "tests", "gpu_api_fuzz.py"), "30", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
