@@ -309,3 +309,13 @@ def test_gzseek_starts_from_the_window_in_front_of_the_chunk(tmp_path):
             "sys.stdout.buffer.write(buf.raw)\n" % (os.path.join(ROOT, "tests"), name))
     r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, timeout=300)
     assert r.returncode == 0 and r.stdout == data[150 << 20:(150 << 20) + 1000], r.stderr[-500:]
+
+
+def test_random_use_of_the_gz_layer():
+    """tests/gpu_gz_fuzz.py: files written with random gzwrite() sizes, modes (plain, chunk index, windows) and chunk
+    sizes are gzip files to Python's gzip, read back whole in random pieces and at random offsets.  (A child process: the
+    tool sets sizes through the environment.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_gz_fuzz.py"), "15", "21"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
