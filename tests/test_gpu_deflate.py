@@ -461,3 +461,13 @@ def test_chunk_offsets_scan(engine, n, base):
     want = np.concatenate(([0], np.cumsum(lens))).astype(np.uint64) + np.uint64(base)
     assert (got == want).all()
     d_len.free(); d_off.free()
+
+
+def test_random_parity_cases():
+    """tests/gpu_parity_fuzz.py: corpus kind, length, level, strategy, memLevel and chunk size at random, and inputs spliced
+    from pieces of different kinds, runs and repeats; bytes and chunk lengths equal the oracle's.  (920 cases were run when
+    the tool was written; forty here.)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_parity_fuzz.py"), "40", "31"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
