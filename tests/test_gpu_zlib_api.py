@@ -988,3 +988,12 @@ def test_random_calls_of_the_stream_api_agree():
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(Z.ROOT, "tests", "gpu_api_fuzz.py"), "30", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_random_streams_of_another_producer_inflate():
+    """tests/gpu_foreign_fuzz.py: streams of Python's zlib (the system's libz) with random levels, strategies, window sizes,
+    wrappers and flush points of every kind, through inflate() with random steps; trailing bytes stay with the caller.
+    (660 cases were run when the tool was written; thirty here.)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(Z.ROOT, "tests", "gpu_foreign_fuzz.py"), "30", "41"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
