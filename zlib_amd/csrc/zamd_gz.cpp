@@ -26,6 +26,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <new>
@@ -40,12 +41,25 @@ namespace {
 enum { GZ_NONE = 0, GZ_READ = 7247, GZ_WRITE = 31153, GZ_APPEND = 1 };   /* gzguts.h:150-153 */
 enum { LOOK = 0, COPY = 1, GZIP = 2 };                                    /* gzguts.h:155-157 */
 
+/* Allocator of the input buffer: resize() leaves new bytes as they are (a buffer grown to a gigabyte for one large
+ * gzread() would otherwise be cleared first, 200 ms that the file's bytes then overwrite). */
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    NoInitAlloc() {}
+    template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&... a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+
 struct GzFile {
     gzFile_s x;                 /* what the gzgetc() macro of zlib.h reads: must come first (gzguts.h:160-162) */
     int mode, fd;
     std::string path;
     unsigned size, want;        /* buffer size in use (0: nothing allocated yet), requested size */
-    std::vector<unsigned char> in, out;
+    int hinting;                /* reading: the member being inflated is the one the file's chunk index describes */
+    unsigned fill;              /* reading: how much input a refill may hold (0: size); a large gzread() raises it for its own calls */
+    std::vector<unsigned char, NoInitAlloc<unsigned char> > in;
+    std::vector<unsigned char> out;
     int direct;
     /* reading */
     int how;
@@ -113,7 +127,7 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
     if (s == NULL) return NULL;
     memset(&s->x, 0, sizeof s->x);
     memset(&s->strm, 0, sizeof s->strm);
-    s->size = 0; s->want = default_want();
+    s->size = 0; s->want = default_want(); s->fill = 0; s->hinting = 0;
     s->mode = GZ_NONE; s->level = Z_DEFAULT_COMPRESSION; s->strategy = Z_DEFAULT_STRATEGY; s->direct = 0;
     s->err = Z_OK; s->how = LOOK; s->eof = s->past = 0; s->seek = 0; s->skip = 0; s->start = 0;
     s->want_index = 0; s->members = 0; s->base = s->produced = s->member_at = s->index_member = 0; s->have_ridx = 0; s->ridx_member = 0;
@@ -185,6 +199,12 @@ gzFile open_file(const char *path, int fd, const char *mode)
 }
 
 /* ------------------------------------------------------------------ reading */
+static double now_ms()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
 int load(GzFile *s, unsigned char *buf, unsigned len, unsigned *have)    /* gz_load, gzread.c:20-42 */
 {
     ssize_t r = 0;
@@ -205,7 +225,8 @@ int refill(GzFile *s)                                   /* gz_avail, gzread.c:51
     if (s->eof == 0) {
         z_stream &z = s->strm;
         if (z.avail_in) memmove(s->in.data(), z.next_in, z.avail_in);
-        unsigned got, want = s->size - z.avail_in;
+        const unsigned room = s->fill > s->size && s->in.size() >= s->fill ? s->fill : s->size;
+        unsigned got, want = room - z.avail_in;
         if (s->read_limit && want > s->read_limit) want = (unsigned)s->read_limit;     /* after a seek: just the chunks asked for */
         if (load(s, s->in.data() + z.avail_in, want, &got) == -1) return -1;
         if (s->read_limit) s->read_limit -= got < s->read_limit ? got : s->read_limit;
@@ -246,10 +267,11 @@ int look(GzFile *s)                                     /* gz_look, gzread.c:86-
         }
         if (s->raw_mode) { inflateReset2(&z, 15 + 16); s->raw_mode = 0; }
         else inflateReset(&z);
+        s->hinting = 0;
         if (s->have_ridx) {
             z_off64_t at = lseek(s->fd, 0, SEEK_CUR);
             if (at != -1 && (uint64_t)at - z.avail_in == s->ridx_member)
-                zamd_inflate_index_hint(&z, s->ridx.data(), (unsigned)(s->ridx.size() / 2));
+                s->hinting = zamd_inflate_index_hint(&z, s->ridx.data(), (unsigned)(s->ridx.size() / 2)) == Z_OK;
         }
         s->how = GZIP; s->direct = 0;
         return 0;
@@ -269,12 +291,19 @@ int decomp(GzFile *s)                                   /* gz_decomp, gzread.c:1
     z_stream &z = s->strm;
     int ret = Z_OK;
     const unsigned had = z.avail_out;
+    static const bool trace = getenv("ZAMD_Z_TRACE") != nullptr;
     do {
-        if (z.avail_in == 0 && refill(s) == -1) return -1;
+        const double t0 = trace ? now_ms() : 0;
+        /* (a large request tops up a buffer that holds less than half of its input first: the input then reaches inflate()
+         * in one piece, and the round is as large as the request) */
+        if ((z.avail_in == 0 || (s->fill && z.avail_in < s->fill / 2 && !s->eof)) && refill(s) == -1) return -1;
+        const double t1 = trace ? now_ms() : 0;
         /* inflate() of this library takes input ahead of its output, so an empty input buffer at the end of
          * the file is the end of the data only once inflate() itself has nothing left to hand over */
         const bool starved = z.avail_in == 0;
+        const unsigned in0 = z.avail_in, out0 = z.avail_out;
         ret = inflate(&z, Z_NO_FLUSH);
+        if (trace) fprintf(stderr, "zamd_gz decomp: refill %.1f ms, inflate %.1f ms (in %u -> %u, out room %u -> %u) rc %d\n", t1 - t0, now_ms() - t1, in0, z.avail_in, out0, z.avail_out, ret);
         if (starved && ret == Z_BUF_ERROR) { set_error(s, Z_BUF_ERROR, "unexpected end of file"); break; }
         if (ret == Z_STREAM_ERROR || ret == Z_NEED_DICT) { set_error(s, Z_STREAM_ERROR, "internal error: inflate stream corrupt"); return -1; }
         if (ret == Z_MEM_ERROR) { set_error(s, Z_MEM_ERROR, "out of memory"); return -1; }
@@ -780,14 +809,52 @@ static int gzread_body(gzFile file, voidp buf, unsigned len)                    
             memcpy(buf, s->x.next, n);
             s->x.next += n; s->x.have -= n;
         } else if (at_end(s)) { s->past = 1; break; }
-        else if (s->how == LOOK || len < (s->size << 1)) {      /* small request or new member: through the buffer */
+        else if (s->how == LOOK && len >= ((s->size ? s->size : s->want) << 1)) {      /* a large request at a member's start: find out what follows, */
+            if (look(s) == -1) return -1;                                  /* then straight into the caller's memory as well */
+            if (s->how == LOOK && s->x.have == 0 && s->strm.avail_in == 0 && s->eof) { s->past = 1; break; }
+            continue;
+        } else if (s->how == LOOK || len < (s->size << 1)) {      /* small request or new member: through the buffer */
             if (fetch(s) == -1) return -1;
             continue;
         } else if (s->how == COPY) {                            /* large request: straight into the caller's memory */
             if (load(s, (unsigned char *)buf, len, &n) == -1) return -1;
         } else {
+            /* inflate() of this library runs at what one call holds: a request of hundreds of megabytes gets input to
+             * match (about what it inflates from, the request's own size at most), not one buffer of 32 MiB at a time —
+             * that is a round of some seventy chunks, as slow as a round of thousands */
+            static const uint64_t big_cap = [] { const char *v = getenv("ZAMD_GZ_READ_MIB"); uint64_t m = v ? strtoull(v, nullptr, 10) : 1024; return (m > 2047 ? 2047 : m) << 20; }();
+            /* how much input the request inflates from: by the chunk index when the file has one (inflate() then places
+             * exactly those chunks, straight into the caller's memory), else by what the data has compressed to so far.
+             * Input beyond the request would be inflated ahead into a buffer of inflate()'s own and copied from there. */
+            uint64_t want_in = len;
+            const uint64_t done = zamd_inflate_hinted_chunks(&z);
+            if (s->have_ridx && s->hinting && done < s->ridx.size() / 2) {
+                uint64_t comp = 0, raw = 0;
+                for (size_t k = (size_t)done; k < s->ridx.size() / 2 && raw < len; k++) { comp += s->ridx[2 * k]; raw += s->ridx[2 * k + 1]; }
+                want_in = comp + 64;
+            } else if (z.total_in > (1u << 20) && z.total_out > z.total_in) {
+                want_in = (uint64_t)((double)len * ((double)z.total_in / (double)z.total_out) * 1.02) + 65536;
+            }
+            if (want_in > big_cap) want_in = big_cap;
+            if (want_in > s->size && big_cap) {
+                if (s->in.size() < want_in) {
+                    /* a new buffer with some room to spare (the next request's chunks may be a little larger); only the
+                     * bytes still waiting move over */
+                    uint64_t cap = want_in + (want_in >> 3);
+                    if (cap > big_cap) cap = big_cap;
+                    try {
+                        std::vector<unsigned char, NoInitAlloc<unsigned char> > bigger((size_t)cap);
+                        if (z.avail_in) memcpy(bigger.data(), z.next_in, z.avail_in);
+                        s->in.swap(bigger);
+                        z.next_in = s->in.data();
+                    } catch (...) { want_in = s->in.size(); }
+                }
+                s->fill = (unsigned)want_in;
+            }
             z.avail_out = len; z.next_out = (Bytef *)buf;
-            if (decomp(s) == -1) return -1;
+            const int rc = decomp(s);
+            s->fill = 0;
+            if (rc == -1) return -1;
             n = s->x.have; s->x.have = 0;
         }
         len -= n; buf = (char *)buf + n; got += n; s->x.pos += n;
@@ -796,6 +863,9 @@ static int gzread_body(gzFile file, voidp buf, unsigned len)                    
 }
 int gzread(gzFile file, voidp buf, unsigned len)
 {
+    static const bool trace = getenv("ZAMD_Z_TRACE") != nullptr;
+    const double t0 = trace ? now_ms() : 0;
+    struct Done { double t0; unsigned len; bool on; ~Done() { if (on) fprintf(stderr, "zamd_gz gzread(%u): %.1f ms\n", len, now_ms() - t0); } } done = {t0, len, trace};
     try { return gzread_body(file, buf, len); }
     catch (...) { return -1; }      /* an allocation failed: the call fails, nothing is thrown at a C caller */
 }

@@ -1280,8 +1280,11 @@ const int NO_PROGRESS = 100, HINT_MISFIT = 101;
 inline void drop_hints(IState *s) { s->hints.clear(); s->hint_pos = 0; s->hint_splits.clear(); s->hint_per = 0; }
 int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t ext_n = 0) {
     const bool view = ext != nullptr;
+    // view with bytes in the buffer (the rest of a chunk that an earlier call left there): the input is those bytes and,
+    // behind them, the caller's; it becomes one piece on the device, and nothing is copied on the host
+    const size_t pre_n = view ? s->in.size() : 0;
     const uint8_t *const ip = view ? ext : s->in.data();
-    const size_t in_n = view ? ext_n : s->in.size();
+    const size_t in_n = view ? pre_n + ext_n : s->in.size();
     Longs view_cands(s->cands.get_allocator()); size_t view_scanned = 0;
     Longs &cands = view ? view_cands : s->cands;
     size_t &scanned = view ? view_scanned : s->scanned;
@@ -1298,7 +1301,8 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     auto need_input = [&]() -> int {
         if (on_device) return Z_OK;
         if (grow(e, &g_gpu.d_in, &g_gpu.in_cap, in_n + 64) != Z_OK) return Z_MEM_ERROR;
-        if ((in_n >= (32u << 20) ? zamd_dev_upload_staged : zamd_dev_upload)(e, g_gpu.d_in, ip, in_n) != 0) return Z_MEM_ERROR;
+        if (pre_n && zamd_dev_upload(e, g_gpu.d_in, s->in.data(), pre_n) != 0) return Z_MEM_ERROR;
+        if ((in_n - pre_n >= (32u << 20) ? zamd_dev_upload_staged : zamd_dev_upload)(e, g_gpu.d_in + pre_n, ip, in_n - pre_n) != 0) return Z_MEM_ERROR;
         on_device = true;
         tr.lap("upload");
         return Z_OK;
@@ -1368,6 +1372,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
                 found.resize(cnt);
                 std::sort(found.begin(), found.end());
             } else {                                        // more markers than the list holds: search on the host
+                if (pre_n) return NO_PROGRESS;              // (in two pieces there: the caller buffers them into one)
                 found.clear();
                 static const uint8_t pat[4] = {0, 0, 0xff, 0xff};
                 const uint8_t *base = ip, *end = base + in_n;
@@ -1553,6 +1558,7 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     if (produced && piped) {
         size_t good = 0; uint32_t bad = 0;
         const uint32_t check0 = s->check;
+        if (pre_n && need_input() != Z_OK) return Z_MEM_ERROR;        // two pieces on the host: the groups take their input from the device
         int rc = place_piped(e, s, ip, in_n, on_device ? g_gpu.d_in : nullptr, chain, strm->next_out, group_out, &good, &bad, tr);
         if (rc != 0) { s->check = check0; return Z_MEM_ERROR; }
         if (good == 0) {
@@ -1642,8 +1648,11 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
     size_t drop = (size_t)(end_bit >> 3);
     if (final_block) { drop = (size_t)((end_bit + 7) >> 3); s->bit_off = 0; s->last = true; s->mode = IM_TRAILER; }
     else s->bit_off = (uint32_t)(end_bit & 7);
-    if (view) { strm->next_in += drop; strm->avail_in -= (uInt)drop; strm->total_in += drop; }
-    else {
+    if (view) {
+        const size_t from_buf = drop < pre_n ? drop : pre_n, from_caller = drop - from_buf;
+        if (from_buf) { s->in.erase(s->in.begin(), s->in.begin() + from_buf); s->cands.clear(); s->scanned = 0; }   // what the buffer's own rounds knew about it
+        strm->next_in += from_caller; strm->avail_in -= (uInt)from_caller; strm->total_in += from_caller;
+    } else {
         s->in.erase(s->in.begin(), s->in.begin() + drop);
         if (s->in.empty()) s->tail_partial = 0;
         Longs keep(cands.get_allocator());
@@ -1742,8 +1751,11 @@ static int inflate_body(z_streamp strm, int flush) {
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
     int ret = Z_OK;
     s->call_taken = 0;
+    Trace tc;
+    struct Done { Trace &t; ~Done() { t.done("inflate call"); } } done_tc = {tc};
     for (;;) {
         idrain(strm, s);
+        tc.lap("drain");
         if (s->mode == IM_TRAILER) {
             // Checked in the same call that decoded the final block, so that bytes
             // behind the stream can be handed back to that call's next_in.
@@ -1796,11 +1808,12 @@ static int inflate_body(z_streamp strm, int flush) {
                 s->bit_off = off; s->prime_bits = 0; s->prime_hold = 0;
             }
             bool tried_all = false;
-            if (s->in.empty() && strm->avail_in >= (1u << 20)) {
+            if ((s->in.empty() || (s->in.size() < (4u << 20) && strm->avail_in >= (8u << 20) && !s->tail_partial)) && strm->avail_in >= (1u << 20)) {
                 // a large input is decoded where it lies; what a round does not use stays with the caller
                 static const size_t view_cap = (size_t)env_u64("ZAMD_Z_IN_VIEW_MIB", 2048) << 20;
                 const size_t n = strm->avail_in < view_cap ? strm->avail_in : view_cap;
                 int rc = decode_some(strm, s, strm->next_in, n);
+                tc.lap("round on the caller's input");
                 if (rc == Z_MEM_ERROR) { s->mode = IM_MEM; return Z_MEM_ERROR; }
                 if (rc != NO_PROGRESS) continue;
                 tried_all = n == strm->avail_in;            // not one whole block in there: buffer it and wait for more
@@ -1817,8 +1830,10 @@ static int inflate_body(z_streamp strm, int flush) {
                 strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take; s->call_taken += take;
             }
             if (tried_all) s->tried = s->in.size();
+            tc.lap("input buffered");
             if (s->in.size() == s->tried) break;             // nothing new since the last fruitless attempt
             int rc = decode_some(strm, s);
+            tc.lap("round on buffered input");
             if (rc == Z_MEM_ERROR) { s->mode = IM_MEM; return Z_MEM_ERROR; }
             continue;
         }
