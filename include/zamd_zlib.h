@@ -238,6 +238,7 @@ unsigned long long zamd_inflate_hinted_chunks(z_streamp strm);   /* chunks infla
 typedef struct zamd_gz_index {
     unsigned long long member_offset; unsigned n_chunks; unsigned *pairs;
     unsigned long long window_offset; unsigned window_every, n_windows;      /* file offset of the first window member; 0, 0, 0: none */
+    unsigned long long *splits; unsigned splits_per_chunk;                   /* split records of the chunks (zamd_deflate_index_splits), or NULL, 0 */
 } zamd_gz_index;
 /* chunks placed by index entries since the file was opened, and seeks that started from a stored window */
 int zamd_gz_seek_stats(gzFile file, unsigned long long *chunks_decoded, unsigned long long *window_seeks);

@@ -36,7 +36,8 @@ _lib = None
 
 class GzIndex(C.Structure):
     _fields_ = [("member_offset", C.c_ulonglong), ("n_chunks", C.c_uint), ("pairs", C.POINTER(C.c_uint)),
-                ("window_offset", C.c_ulonglong), ("window_every", C.c_uint), ("n_windows", C.c_uint)]
+                ("window_offset", C.c_ulonglong), ("window_every", C.c_uint), ("n_windows", C.c_uint),
+                ("splits", C.POINTER(C.c_ulonglong)), ("splits_per_chunk", C.c_uint)]
 
 
 def lib():

@@ -116,7 +116,10 @@ def test_gz_file_with_index(tmp_path):
     assert gzip.decompress(blob) == data
     member, pairs, first_index = _parse_index(blob)
     assert member == 0 and sum(r for _, r in pairs) == len(data)
-    assert 10 + sum(c for c, _ in pairs) + 8 == first_index          # header, deflate data, trailer, then the index
+    # header, deflate data, trailer, then one member with the chunks' split records ('ZS': 7 x u64 a chunk), then the index
+    data_end = 10 + sum(c for c, _ in pairs) + 8
+    assert blob[data_end:data_end + 4] == b"\x1f\x8b\x08\x04" and blob[data_end + 12:data_end + 14] == b"ZS" and blob[data_end + 17] == 7
+    assert data_end + 12 + 4 + 16 + 8 * 7 * len(pairs) + 10 == first_index
     cpos, rpos = 10, 0
     for c, r in pairs:
         d = zlib.decompressobj(-15, zdict=data[max(0, rpos - 32768):rpos]) if rpos else zlib.decompressobj(-15)
@@ -127,6 +130,8 @@ def test_gz_file_with_index(tmp_path):
     fd = os.open(name, os.O_RDONLY)
     assert l.zamd_gz_index_load(fd, C.byref(ix)) == 0
     assert ix.member_offset == 0 and [(ix.pairs[2 * i], ix.pairs[2 * i + 1]) for i in range(ix.n_chunks)] == pairs
+    assert ix.splits_per_chunk == 7
+    assert [ix.splits[k] for k in range(7 * ix.n_chunks)] == [int.from_bytes(blob[data_end + 32 + 8 * k:data_end + 40 + 8 * k], "little") for k in range(7 * len(pairs))]
     l.zamd_gz_index_free(C.byref(ix))
     os.close(fd)
     # reading back with the index, in ragged pieces, with a rewind in between

@@ -262,6 +262,11 @@ def test_gzseek_starts_from_the_window_in_front_of_the_chunk(tmp_path):
     ix = Z.GzIndex()
     assert l.zamd_gz_index_load(fd, C.byref(ix)) == 0
     assert ix.n_chunks == 256 and ix.window_every == 1 and ix.n_windows == 255 and 0 < ix.window_offset < size
+    # the index carries the split records of its chunks too (block boundaries: inflate() puts a wavefront on every part)
+    assert ix.splits_per_chunk == 7 and sum(1 for c in range(256) if ix.splits[7 * c]) > 200
+    for c in (0, 100, 255):
+        recs = [ix.splits[7 * c + k] for k in range(7) if ix.splits[7 * c + k]]
+        assert recs == sorted(recs) and all(0 < (r & 0xffffffff) < (1 << 20) and 0 < (r >> 32) < 8 * ix.pairs[2 * c] for r in recs)
     l.zamd_gz_index_free(C.byref(ix))
     os.close(fd)
     assert size < 0.6 * n                                                  # windows cost 3 % of the data, not more

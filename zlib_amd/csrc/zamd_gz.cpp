@@ -70,12 +70,14 @@ struct GzFile {
     int want_index, members;    /* chunk index asked for; gzip members finished so far */
     uint64_t base, produced, member_at;   /* file offset at open, deflate() output so far, where the open member started */
     std::vector<unsigned> index; uint64_t index_member;
+    std::vector<unsigned long long> isplits; unsigned isplits_per;   /* the member's split records (block boundaries inside its chunks), per chunk */
     unsigned win_every, chunk_bytes;      /* windows wanted in front of every win_every-th chunk (0: none); the chunk grid */
     uint64_t upos;                        /* input bytes of the open member handed to deflate() so far */
     std::vector<unsigned char> wtail;     /* the last 32 KiB of them */
     std::vector<std::vector<unsigned char> > windows;
     /* reading */
     std::vector<unsigned> ridx; uint64_t ridx_member; int have_ridx;
+    std::vector<unsigned long long> rsplits; unsigned rsplits_per;   /* split records of the index, rsplits_per to a chunk (0: none) */
     uint64_t ridx_woff; unsigned ridx_wevery, ridx_nwin;   /* where the window members start, their spacing and number */
     uint64_t data_start;                  /* file offset of the indexed member's deflate data (0: not looked up yet) */
     int raw_mode;                         /* inflating from a stored window: raw deflate, the member's trailer is skipped by hand */
@@ -130,7 +132,7 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
     s->size = 0; s->want = default_want(); s->fill = 0; s->hinting = 0;
     s->mode = GZ_NONE; s->level = Z_DEFAULT_COMPRESSION; s->strategy = Z_DEFAULT_STRATEGY; s->direct = 0;
     s->err = Z_OK; s->how = LOOK; s->eof = s->past = 0; s->seek = 0; s->skip = 0; s->start = 0;
-    s->want_index = 0; s->members = 0; s->base = s->produced = s->member_at = s->index_member = 0; s->have_ridx = 0; s->ridx_member = 0;
+    s->want_index = 0; s->members = 0; s->base = s->produced = s->member_at = s->index_member = 0; s->have_ridx = 0; s->ridx_member = 0; s->isplits_per = 0; s->rsplits_per = 0;
     s->win_every = 0; s->chunk_bytes = 0; s->upos = 0;
     s->ridx_woff = 0; s->ridx_wevery = s->ridx_nwin = 0; s->data_start = 0; s->raw_mode = 0; s->skip_trailer = 0; s->read_limit = 0; s->out_limit = 0; s->window_seeks = 0;
     { const char *v = getenv("ZAMD_GZ_INDEX"); if (v && *v && *v != '0') s->want_index = 1; }
@@ -181,6 +183,7 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
                 s->ridx.assign(ix.pairs, ix.pairs + 2 * (size_t)ix.n_chunks);
                 s->ridx_member = ix.member_offset; s->have_ridx = 1;
                 s->ridx_woff = ix.window_offset; s->ridx_wevery = ix.window_every; s->ridx_nwin = ix.n_windows;
+                if (ix.splits && ix.splits_per_chunk) { s->rsplits.assign(ix.splits, ix.splits + (size_t)ix.n_chunks * ix.splits_per_chunk); s->rsplits_per = ix.splits_per_chunk; }
                 zamd_gz_index_free(&ix);
             }
             lseek(s->fd, s->start, SEEK_SET);
@@ -272,6 +275,7 @@ int look(GzFile *s)                                     /* gz_look, gzread.c:86-
             z_off64_t at = lseek(s->fd, 0, SEEK_CUR);
             if (at != -1 && (uint64_t)at - z.avail_in == s->ridx_member)
                 s->hinting = zamd_inflate_index_hint(&z, s->ridx.data(), (unsigned)(s->ridx.size() / 2)) == Z_OK;
+            if (s->hinting && s->rsplits_per) (void)zamd_inflate_index_hint_splits(&z, s->rsplits.data(), s->rsplits_per);
         }
         s->how = GZIP; s->direct = 0;
         return 0;
@@ -446,7 +450,12 @@ int comp(GzFile *s, int flush)                          /* gz_comp, gzwrite.c:74
         if (s->want_index) {                            /* the index of the member that just ended, before the reset forgets it */
             const unsigned *pairs; unsigned n;
             s->index.clear();
-            if (s->members == 0 && zamd_deflate_index_get(&z, &pairs, &n) == Z_OK) { s->index.assign(pairs, pairs + 2 * (size_t)n); s->index_member = s->base + s->member_at; }
+            if (s->members == 0 && zamd_deflate_index_get(&z, &pairs, &n) == Z_OK) {
+                s->index.assign(pairs, pairs + 2 * (size_t)n); s->index_member = s->base + s->member_at;
+                const unsigned long long *recs; unsigned per = 0;
+                s->isplits.clear(); s->isplits_per = 0;
+                if (zamd_deflate_index_splits(&z, &recs, &per) == Z_OK && per) { s->isplits.assign(recs, recs + (size_t)per * n); s->isplits_per = per; }
+            }
         }
         s->members++;
         s->member_at = s->produced;
@@ -491,6 +500,13 @@ void put64(std::vector<unsigned char> &v, uint64_t x) { put32(v, (uint32_t)x); p
  * says where they start: with flags bit 1 set its payload holds, in front of the closing 12 bytes,
  * u64 offset in the file of the first window member, u32 spacing in chunks, u32 number of windows. */
 const unsigned WIN_MEMBER = 10 + 2 + 4 + 8 + 32768 + 10;
+/* Split members: the same empty gzip member with the subfield 'Z' 'S': u8 version (1), u8 records per chunk, u16 0, u32 n,
+ * u64 number of the first chunk listed, n x records-per-chunk x u64 split records (zamd_deflate_index_splits: block
+ * boundaries inside the chunk, (bit offset in the chunk) << 32 | offset in the chunk's data, unused ones 0), at most
+ * SPLITS_PER_MEMBER chunks to a member (a subfield holds 65 531 bytes).  They stand behind the window members; with flags
+ * bit 2 set the last index member's payload holds, behind the window fields, u64 offset in the file of the first split
+ * member, u32 records per chunk, u32 number of split members.  With them inflate() puts several wavefronts on a chunk. */
+const unsigned SPLITS_PER_MEMBER = 1000;
 int write_index(GzFile *s)
 {
     const size_t nch = s->index.size() / 2;
@@ -510,19 +526,36 @@ int write_index(GzFile *s)
         for (int k = 0; k < 8; k++) o.push_back(0);
         if (o.size() >= (8u << 20)) { if (write_all(s, o.data(), o.size()) == -1) return -1; o.clear(); }
     }
-    const uint64_t first_member = first_window + (uint64_t)nwin * WIN_MEMBER;
+    const uint64_t first_split = first_window + (uint64_t)nwin * WIN_MEMBER;
+    const unsigned per = s->isplits_per && s->isplits_per <= 8 && s->isplits.size() == nch * (size_t)s->isplits_per ? s->isplits_per : 0u;
+    uint64_t split_bytes = 0; unsigned nsplit = 0;
+    for (size_t c0 = 0; per && c0 < nch; c0 += SPLITS_PER_MEMBER) {
+        const size_t n = nch - c0 < SPLITS_PER_MEMBER ? nch - c0 : SPLITS_PER_MEMBER;
+        const unsigned payload = 16u + 8u * per * (unsigned)n;
+        o.insert(o.end(), head, head + 10);
+        put16(o, payload + 4u);
+        o.push_back('Z'); o.push_back('S'); put16(o, payload);
+        o.push_back(1); o.push_back((unsigned char)per); put16(o, 0); put32(o, (uint32_t)n); put64(o, c0);
+        for (size_t k = c0 * per; k < (c0 + n) * per; k++) put64(o, s->isplits[k]);
+        o.push_back(3); o.push_back(0);
+        for (int k = 0; k < 8; k++) o.push_back(0);
+        split_bytes += 12u + payload + 4u + 10u; nsplit++;
+        if (o.size() >= (8u << 20)) { if (write_all(s, o.data(), o.size()) == -1) return -1; o.clear(); }
+    }
+    const uint64_t first_member = first_split + split_bytes;
     for (size_t c0 = 0; c0 < nch; c0 += IDX_PER_MEMBER) {
         const size_t n = nch - c0 < IDX_PER_MEMBER ? nch - c0 : IDX_PER_MEMBER;
         const bool last = c0 + n == nch;
-        const bool wins = last && nwin != 0;
-        const unsigned payload = 24u + 8u * (unsigned)n + (wins ? 16u : 0u) + (last ? 12u : 0u);
+        const bool wins = last && nwin != 0, spl = last && nsplit != 0;
+        const unsigned payload = 24u + 8u * (unsigned)n + (wins ? 16u : 0u) + (spl ? 16u : 0u) + (last ? 12u : 0u);
         o.insert(o.end(), head, head + 10);
         put16(o, payload + 4u);
         o.push_back('Z'); o.push_back('I'); put16(o, payload);
-        o.push_back(1); o.push_back((last ? 1 : 0) | (wins ? 2 : 0)); put16(o, 0); put32(o, (uint32_t)n);
+        o.push_back(1); o.push_back((last ? 1 : 0) | (wins ? 2 : 0) | (spl ? 4 : 0)); put16(o, 0); put32(o, (uint32_t)n);
         put64(o, s->index_member); put64(o, c0);
         for (size_t c = c0; c < c0 + n; c++) { put32(o, s->index[2 * c]); put32(o, s->index[2 * c + 1]); }
         if (wins) { put64(o, first_window); put32(o, s->win_every); put32(o, (uint32_t)nwin); }
+        if (spl) { put64(o, first_split); put32(o, per); put32(o, nsplit); }
         if (last) { put64(o, first_member); o.push_back('Z'); o.push_back('A'); o.push_back('M'); o.push_back('I'); }
         o.push_back(3); o.push_back(0);
         for (int k = 0; k < 8; k++) o.push_back(0);
@@ -591,6 +624,7 @@ int window_seek(GzFile *s, z_off64_t target)
         set_error(s, Z_STREAM_ERROR, "internal error: inflate stream corrupt");
         return -1;
     }
+    if (s->rsplits_per) (void)zamd_inflate_index_hint_splits(&z, s->rsplits.data() + a * (size_t)s->rsplits_per, s->rsplits_per);
     z.avail_in = 0; z.next_in = s->in.data();
     s->x.have = 0; s->eof = 0; s->past = 0; s->seek = 0; s->skip_trailer = 0;
     set_error(s, Z_OK, NULL);
@@ -624,7 +658,7 @@ int zamd_gz_index_load(int fd, zamd_gz_index *out)
     uint64_t at = rd(tail, 8);
     if (at >= (uint64_t)end) return -1;
     std::vector<unsigned> pairs;
-    uint64_t member = 0;
+    uint64_t member = 0, split_at = 0; unsigned split_per = 0, split_members = 0;
     for (;;) {
         unsigned char h[16 + 24];
         if (at + sizeof h > (uint64_t)end || pread(fd, h, sizeof h, (off_t)at) != (ssize_t)sizeof h) return -1;
@@ -632,14 +666,18 @@ int zamd_gz_index_load(int fd, zamd_gz_index *out)
         const unsigned xlen = (unsigned)rd(h + 10, 2), plen = (unsigned)rd(h + 14, 2);
         const unsigned flags = h[17];
         const uint64_t n = rd(h + 20, 4), first = rd(h + 32, 8);
-        const unsigned ext = (flags & 2) ? 16u : 0u;
+        const unsigned ext = ((flags & 2) ? 16u : 0u) + ((flags & 4) ? 16u : 0u);
         if (plen + 4u != xlen || plen != 24u + 8u * n + ext + ((flags & 1) ? 12u : 0u) || first != pairs.size() / 2) return -1;
-        if ((flags & 2) && !(flags & 1)) return -1;
+        if ((flags & 6) && !(flags & 1)) return -1;
         if (pairs.empty()) member = rd(h + 24, 8); else if (member != rd(h + 24, 8)) return -1;
         std::vector<unsigned char> body(8 * n + ext);
         if (!body.empty() && pread(fd, body.data(), body.size(), (off_t)(at + sizeof h)) != (ssize_t)body.size()) return -1;
         for (uint64_t i = 0; i < 2 * n; i++) pairs.push_back((unsigned)rd(body.data() + 4 * i, 4));
-        if (ext) {
+        if (flags & 4) {
+            const unsigned char *q = body.data() + 8 * n + ((flags & 2) ? 16u : 0u);
+            split_at = rd(q, 8); split_per = (unsigned)rd(q + 8, 4); split_members = (unsigned)rd(q + 12, 4);
+        }
+        if (flags & 2) {
             out->window_offset = rd(body.data() + 8 * n, 8);
             out->window_every = (unsigned)rd(body.data() + 8 * n + 8, 4);
             out->n_windows = (unsigned)rd(body.data() + 8 * n + 12, 4);
@@ -654,10 +692,33 @@ int zamd_gz_index_load(int fd, zamd_gz_index *out)
     if (!pairs.empty()) memcpy(out->pairs, pairs.data(), pairs.size() * sizeof(unsigned));
     out->n_chunks = (unsigned)(pairs.size() / 2);
     out->member_offset = member;
+    /* the split records: hints, so anything about them that does not add up just leaves them out */
+    if (split_members && split_per && split_per <= 8) {
+        std::vector<unsigned long long> recs;
+        uint64_t sat = split_at; bool ok = true;
+        for (unsigned m = 0; ok && m < split_members; m++) {
+            unsigned char h[16 + 16];
+            ok = sat + sizeof h <= (uint64_t)end && pread(fd, h, sizeof h, (off_t)sat) == (ssize_t)sizeof h && h[0] == 0x1f && h[1] == 0x8b && h[3] == 4 &&
+                 h[12] == 'Z' && h[13] == 'S' && h[16] == 1 && h[17] == split_per;
+            if (!ok) break;
+            const unsigned xlen = (unsigned)rd(h + 10, 2), plen = (unsigned)rd(h + 14, 2);
+            const uint64_t n = rd(h + 20, 4), first = rd(h + 24, 8);
+            ok = plen + 4u == xlen && plen == 16u + 8u * split_per * n && first * split_per == recs.size();
+            if (!ok) break;
+            std::vector<unsigned char> body(8 * (size_t)split_per * n);
+            ok = body.empty() || pread(fd, body.data(), body.size(), (off_t)(sat + sizeof h)) == (ssize_t)body.size();
+            for (uint64_t i = 0; ok && i < split_per * n; i++) recs.push_back(rd(body.data() + 8 * i, 8));
+            sat += 12 + xlen + 10;
+        }
+        if (ok && recs.size() == (size_t)out->n_chunks * split_per) {
+            out->splits = (unsigned long long *)malloc(recs.size() * sizeof(unsigned long long) + 1);
+            if (out->splits) { if (!recs.empty()) memcpy(out->splits, recs.data(), recs.size() * sizeof(unsigned long long)); out->splits_per_chunk = split_per; }
+        }
+    }
     return 0;
 }
 
-void zamd_gz_index_free(zamd_gz_index *ix) { if (ix) { free(ix->pairs); ix->pairs = NULL; ix->n_chunks = 0; } }
+void zamd_gz_index_free(zamd_gz_index *ix) { if (ix) { free(ix->pairs); free(ix->splits); ix->pairs = NULL; ix->splits = NULL; ix->n_chunks = 0; ix->splits_per_chunk = 0; } }
 
 int zamd_gz_seek_stats(gzFile file, unsigned long long *chunks_decoded, unsigned long long *window_seeks)
 {
