@@ -166,6 +166,10 @@ template <class T> struct ZAlloc {
         return (T *)p;
     }
     void deallocate(T *p, size_t) { zf(opaque, p); }
+    // resize() leaves new elements as they are (bytes, words: a buffer that a download or a copy is about to fill is not
+    // cleared first; every resize() of these vectors either shrinks them or is followed by exactly that)
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class A0, class... A> void construct(U *p, A0 &&a0, A &&... a) { ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
     template <class U> bool operator==(const ZAlloc<U> &o) const { return za == o.za && zf == o.zf && opaque == o.opaque; }
     template <class U> bool operator!=(const ZAlloc<U> &o) const { return !(*this == o); }
 };
@@ -914,6 +918,8 @@ static int deflate_body(z_streamp strm, int flush) {
         } else {
             uint64_t take = s->batch_bytes - s->in.size();
             if (take > strm->avail_in) take = strm->avail_in;
+            // a caller that writes by the megabyte fills the batch: room for all of it at once, not by doubling and copying
+            if (s->in.capacity() < s->batch_bytes && s->in.size() + take > (16u << 20)) s->in.reserve(s->batch_bytes);
             s->in.insert(s->in.end(), strm->next_in, strm->next_in + take);
             strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take;
             if (s->in.size() < s->batch_bytes || (flushing && strm->avail_in == 0)) break;     // (a full batch that is the flush's own: finish_batch)
