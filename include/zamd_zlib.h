@@ -228,6 +228,10 @@ int zamd_z_last_error(void);
 /* The same index kept in a gzip file: gzopen(path, "wbI") (or ZAMD_GZ_INDEX=1) appends it as empty gzip members
  * that every gzip reader skips; gzopen for reading finds and uses it (ZAMD_GZ_INDEX=0: ignores it). */
 unsigned zamd_deflate_chunk_bytes(z_streamp strm);          /* the chunk size of this stream's grid (input bytes) */
+/* What deflate() collects before the engine runs: input handed over in pieces of exactly this size, with nothing
+ * buffered in front, is compressed where it lies.  No counterpart in the reference (deflate.c:1409-1413 sizes the
+ * reference's own unit of work, the window). */
+unsigned long long zamd_deflate_batch_bytes(z_streamp strm);
 unsigned long long zamd_inflate_hinted_chunks(z_streamp strm);   /* chunks inflate() has placed by their index entries so far */
 /* Random access (the reference keeps such access points in memory while it inflates a file once, examples/zran.c:67-72,
  * 249-349): a file written with a 'W' in the mode string (or ZAMD_GZ_WINDOWS=n in the environment: every n-th chunk) also

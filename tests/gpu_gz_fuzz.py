@@ -23,22 +23,35 @@ for case in range(cases):
     chunk = rng.choice([65536, 262144, 1 << 20])
     os.environ["ZAMD_Z_CHUNK"] = str(chunk)
     os.environ["ZAMD_Z_BATCH_MIB"] = str(rng.choice([1, 2, 512]))
+    os.environ["ZAMD_GZ_BUF_MIB"] = rng.choice(["1", "32"])       # (1 MiB with batches of 2: writes collected behind the caller fill their buffers)
+    os.environ["ZAMD_GZ_BEHIND"] = rng.choice(["1", "1", "0"])
     n = rng.choice([rng.randrange(1, len(pool)), rng.randrange(1, 20) << 20, 1, 100])
     off = rng.randrange(0, len(pool) - n + 1)
     data = pool[off:off + n]
     mode = rng.choice(["wb", "wb6I", "wb6W", "wb1W", "wb9I"])
     path = os.path.join(tmp, "f%d.gz" % case).encode()
-    desc = dict(case=case, n=n, chunk=chunk, mode=mode, batch=os.environ["ZAMD_Z_BATCH_MIB"])
+    desc = dict(case=case, n=n, chunk=chunk, mode=mode, batch=os.environ["ZAMD_Z_BATCH_MIB"], buf=os.environ["ZAMD_GZ_BUF_MIB"], behind=os.environ["ZAMD_GZ_BEHIND"])
     g = l.gzopen(path, mode.encode())
     assert g
     at = 0
     while at < n:
         k = min(n - at, rng.choice([1, 4096, rng.randrange(1, 1 << 20), rng.randrange(1, 8 << 20)]))
-        w = l.gzwrite(g, data[at:at + k], k)
-        assert w == k, (desc, w, k)
+        what = rng.random()
+        if what < 0.03:
+            assert l.gzputc(g, data[at]) == data[at], desc
+            k = 1
+        else:
+            w = l.gzwrite(g, data[at:at + k], k)
+            assert w == k, (desc, w, k)
         at += k
-        if rng.random() < 0.05:
+        assert l.gztell(g) == at, (desc, at)
+        what = rng.random()
+        if what < 0.05:
             assert l.gzflush(g, Z.Z_SYNC_FLUSH) == 0
+        elif what < 0.08 and mode == "wb":
+            assert l.gzsetparams(g, rng.choice([1, 6, 9]), 0) == 0
+        elif what < 0.11:
+            assert l.gzoffset(g) >= 0
     assert l.gzclose(g) == 0
     ok = True
     try:

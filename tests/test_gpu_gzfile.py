@@ -241,6 +241,69 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
+def test_writes_collected_behind_the_caller_give_the_same_file(tmp_path):
+    """gzwrite() collects writes of some size in buffers of deflate()'s batch size and compresses a full one on a thread
+    of the file's own.  What the file holds must not depend on it (deflate() does not care how its input is cut,
+    zlib.h:252-262): the same calls with ZAMD_GZ_BEHIND=0 give the same bytes; putc, printf, a flush, a seek and a write
+    larger than the buffers lie between the collected writes (gzwrite.c:165-243, 311-373, 478-510).  Then the thread's
+    engine call fails: a later call reports it, and gzclose does.  (A child process: sizes come from the environment.)"""
+    script = r'''
+import ctypes as C, gzip, os, sys
+sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ["ZAMD_Z_BATCH_MIB"] = "2"
+os.environ["ZAMD_Z_CHUNK"] = "262144"
+os.environ["ZAMD_GZ_BUF_MIB"] = "1"
+import _zapi as Z
+import zlib_amd
+l = Z.lib()
+data = bytes(zlib_amd.corpus(14 << 20, 4, 31))
+def write(name, behind):
+    os.environ["ZAMD_GZ_BEHIND"] = behind
+    g = l.gzopen(name, b"wb6I")
+    want = bytearray()
+    at = 0
+    def put(k):
+        nonlocal at
+        assert l.gzwrite(g, data[at:at + k], k) == k
+        want.extend(data[at:at + k]); at += k
+        assert l.gztell(g) == len(want)
+    put(1000)                                   # small: the file's own buffer
+    for _ in range(5): put(700000)              # collected; the buffer fills and goes to the thread
+    assert l.gzputc(g, 65) == 65; want.append(65)
+    put(600000)
+    assert l.gzprintf(C.c_void_p(g), b"%%s-%%d", b"abc", 7) == 5; want.extend(b"abc-7")
+    put(3 << 20)                                # larger than a buffer: from the caller's memory
+    for _ in range(3): put(900001)
+    assert l.gzflush(g, Z.Z_SYNC_FLUSH) == 0
+    assert l.gzoffset(g) > 0
+    assert l.gzseek(g, 5000, 1) == len(want) + 5000; want.extend(bytes(5000))
+    for _ in range(4): put(524288)
+    assert l.gzclose(g) == 0
+    return bytes(want)
+a, b = sys.argv[1].encode(), sys.argv[2].encode()
+want = write(a, "1")
+assert write(b, "0") == want
+assert open(a, "rb").read() == open(b, "rb").read()
+assert gzip.open(a.decode()).read() == want
+g = l.gzopen(a, b"rb")
+buf = C.create_string_buffer(len(want) + 1)
+assert l.gzread(g, buf, len(want) + 1) == len(want) and buf.raw[:len(want)] == want
+l.gzclose(g)
+# the thread's engine call fails
+os.environ["ZAMD_GZ_BEHIND"] = "1"
+os.environ["ZAMD_Z_FAIL_DEFLATE_AFTER"] = "0"
+g = l.gzopen(b, b"wb6")
+sent = [l.gzwrite(g, data[:700000], 700000) for _ in range(8)]      # the third fills the buffer, the sixth waits for its job
+assert sent[0] == 700000 and sent[-1] == 0, sent
+err = C.c_int(0)
+assert l.gzerror(g, C.byref(err)) == b"out of memory" and err.value == Z.Z_MEM_ERROR
+assert l.gzclose(g) == Z.Z_MEM_ERROR
+print("ok")
+''' % ROOT
+    r = subprocess.run([os.sys.executable, "-c", script, str(tmp_path / "a.gz"), str(tmp_path / "b.gz")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_gzseek_starts_from_the_window_in_front_of_the_chunk(tmp_path):
     """A file written with 'W' stores the 32 KiB in front of every chunk beside the index (what examples/zran.c:67-72 keeps
     in memory): gzseek to any offset then inflates one chunk, not the file from its start.  256 MiB, 20 random offsets,

@@ -29,8 +29,11 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" int zamd_gz_index_load(int fd, zamd_gz_index *out);
@@ -89,6 +92,16 @@ struct GzFile {
     /* error */
     int err; std::string msg;
     z_stream strm;
+    /* Writing behind the caller's back: writes of a megabyte or more are collected in one of two buffers of deflate()'s
+     * batch size; a full one goes to a thread of this file's own, which runs comp() on it (deflate() takes a whole batch
+     * where it lies) while the caller fills the other.  One job at a time.  While a job is out, strm, out, err, msg, the
+     * file position and the index fields belong to that thread: the caller's side touches `carry`, `cur`, `behind_job`,
+     * x.pos and the seek request only, and everything else after wait_idle(). */
+    unsigned char *carry[2]; size_t carry_n[2], carry_cap; int cur;
+    bool behind_job;                      /* a job is out and has not been waited for */
+    std::thread worker; bool worker_on;
+    std::mutex wmu; std::condition_variable wcv;
+    const unsigned char *job_p; size_t job_n; bool job_ready, job_done, wquit;   /* under wmu */
 };
 
 inline GzFile *gz(gzFile f) { return (GzFile *)f; }
@@ -134,6 +147,8 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
     s->err = Z_OK; s->how = LOOK; s->eof = s->past = 0; s->seek = 0; s->skip = 0; s->start = 0;
     s->want_index = 0; s->members = 0; s->base = s->produced = s->member_at = s->index_member = 0; s->have_ridx = 0; s->ridx_member = 0; s->isplits_per = 0; s->rsplits_per = 0;
     s->win_every = 0; s->chunk_bytes = 0; s->upos = 0;
+    s->carry[0] = s->carry[1] = NULL; s->carry_n[0] = s->carry_n[1] = 0; s->carry_cap = 0; s->cur = 0; s->behind_job = false;
+    s->worker_on = false; s->job_p = NULL; s->job_n = 0; s->job_ready = s->job_done = s->wquit = false;
     s->ridx_woff = 0; s->ridx_wevery = s->ridx_nwin = 0; s->data_start = 0; s->raw_mode = 0; s->skip_trailer = 0; s->read_limit = 0; s->out_limit = 0; s->window_seeks = 0;
     { const char *v = getenv("ZAMD_GZ_INDEX"); if (v && *v && *v != '0') s->want_index = 1; }
     { const char *v = getenv("ZAMD_GZ_WINDOWS"); if (v && atoi(v) > 0) { s->win_every = (unsigned)atoi(v); s->want_index = 1; } }
@@ -372,6 +387,10 @@ int winit(GzFile *s)                                    /* gz_init, gzwrite.c:15
         }
         if (s->want_index) zamd_deflate_index(&z, 1);
         s->chunk_bytes = zamd_deflate_chunk_bytes(&z);
+        /* collecting whole batches pays where the caller's pieces are smaller than one (ZAMD_GZ_BEHIND=0: never) */
+        const char *v = getenv("ZAMD_GZ_BEHIND");
+        const unsigned long long batch = zamd_deflate_batch_bytes(&z);
+        s->carry_cap = (v && *v == '0') || batch < 2ull * s->want || batch > (1ull << 30) ? 0 : (size_t)batch;
     }
     s->size = s->want;
     if (!s->direct) { z.avail_out = s->size; z.next_out = s->out.data(); s->x.next = z.next_out; }
@@ -463,6 +482,91 @@ int comp(GzFile *s, int flush)                          /* gz_comp, gzwrite.c:74
         if (s->want_index) zamd_deflate_index(&z, 1);
     }
     return 0;
+}
+
+/* ------------------------------------------------------------------ the thread that compresses behind the caller */
+void worker_loop(GzFile *s)
+{
+    for (;;) {
+        const unsigned char *p; size_t n;
+        {
+            std::unique_lock<std::mutex> g(s->wmu);
+            s->wcv.wait(g, [&] { return s->job_ready || s->wquit; });
+            if (s->wquit) return;
+            s->job_ready = false; p = s->job_p; n = s->job_n;
+        }
+        s->strm.next_in = (Bytef *)p; s->strm.avail_in = (uInt)n;
+        try { (void)comp(s, Z_NO_FLUSH); }
+        catch (...) { s->strm.avail_in = 0; set_error(s, Z_MEM_ERROR, "out of memory"); }
+        { std::lock_guard<std::mutex> g(s->wmu); s->job_done = true; }
+        s->wcv.notify_all();
+    }
+}
+/* After this the file's state is the caller's to read again. */
+void wait_idle(GzFile *s)
+{
+    if (!s->behind_job) return;
+    std::unique_lock<std::mutex> g(s->wmu);
+    s->wcv.wait(g, [&] { return s->job_done; });
+    s->behind_job = false;
+}
+/* The same without waiting: true when no job is out (any more). */
+bool idle(GzFile *s)
+{
+    if (!s->behind_job) return true;
+    std::lock_guard<std::mutex> g(s->wmu);
+    if (!s->job_done) return false;
+    s->behind_job = false;
+    return true;
+}
+inline bool behind(const GzFile *s) { return s->behind_job || s->carry_n[s->cur] != 0; }
+/* Hand the buffer in use to the thread (when the one before is done) and go on in the other one.  -1: the file is in
+ * error (the buffer's bytes are dropped like everything else that is written then). */
+int submit(GzFile *s)
+{
+    wait_idle(s);
+    const int k = s->cur;
+    const size_t n = s->carry_n[k];
+    s->carry_n[k] = 0;
+    if (s->err != Z_OK) return -1;
+    if (n == 0) return 0;
+    if (!s->worker_on) {
+        try { s->worker = std::thread(worker_loop, s); s->worker_on = true; }
+        catch (...) { s->worker_on = false; }
+    }
+    if (!s->worker_on || !s->carry[k ^ 1]) {
+        /* no thread, or no second buffer yet and none to be had: this thread does the work */
+        if (s->worker_on && (s->carry[k ^ 1] = (unsigned char *)malloc(s->carry_cap)) != NULL) { /* go on below */ }
+        else {
+            s->strm.next_in = s->carry[k]; s->strm.avail_in = (uInt)n;
+            return comp(s, Z_NO_FLUSH);
+        }
+    }
+    { std::lock_guard<std::mutex> g(s->wmu); s->job_p = s->carry[k]; s->job_n = n; s->job_ready = true; s->job_done = false; }
+    s->behind_job = true;
+    s->wcv.notify_all();
+    s->cur = k ^ 1;
+    return 0;
+}
+/* Everything collected so far goes through deflate(), and the state is the caller's again.  -1: the file is in error. */
+int settle(GzFile *s)
+{
+    if (!behind(s)) return s->err == Z_OK ? 0 : -1;
+    int rc = submit(s);
+    wait_idle(s);
+    return rc == -1 || s->err != Z_OK ? -1 : 0;
+}
+void stop_worker(GzFile *s)
+{
+    wait_idle(s);
+    if (s->worker_on) {
+        { std::lock_guard<std::mutex> g(s->wmu); s->wquit = true; }
+        s->wcv.notify_all();
+        s->worker.join();
+        s->worker_on = false;
+    }
+    free(s->carry[0]); free(s->carry[1]);
+    s->carry[0] = s->carry[1] = NULL; s->carry_n[0] = s->carry_n[1] = 0;
 }
 
 int zeros(GzFile *s, z_off64_t len)                     /* gz_zero, gzwrite.c:134-162 */
@@ -763,7 +867,9 @@ int gzrewind(gzFile file)                                                       
 static z_off64_t gzseek64_body(gzFile file, z_off64_t offset, int whence)                                   /* gzlib.c:362-436 */
 {
     GzFile *s = gz(file);
-    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE) || fatal(s)) return -1;
+    if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return -1;
+    if (s->mode == GZ_WRITE) (void)settle(s);
+    if (fatal(s)) return -1;
     if (whence != SEEK_SET && whence != SEEK_CUR) return -1;
     if (whence == SEEK_SET) offset -= s->x.pos;
     else if (s->seek) offset += s->skip;
@@ -824,6 +930,7 @@ z_off64_t gzoffset64(gzFile file)                                               
 {
     GzFile *s = gz(file);
     if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return -1;
+    if (s->mode == GZ_WRITE) wait_idle(s);              /* (what is collected and not yet compressed is in no file) */
     z_off64_t off = lseek(s->fd, 0, SEEK_CUR);
     if (off == -1) return -1;
     if (s->mode == GZ_READ) off -= s->strm.avail_in;
@@ -842,6 +949,7 @@ const char *gzerror(gzFile file, int *errnum)                                   
 {
     GzFile *s = gz(file);
     if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return NULL;
+    if (s->mode == GZ_WRITE) wait_idle(s);
     if (errnum != NULL) *errnum = s->err;
     return s->err == Z_MEM_ERROR ? "out of memory" : s->msg.c_str();
 }
@@ -850,6 +958,7 @@ void gzclearerr(gzFile file)                                                    
 {
     GzFile *s = gz(file);
     if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return;
+    if (s->mode == GZ_WRITE) wait_idle(s);
     if (s->mode == GZ_READ) { s->eof = 0; s->past = 0; }
     set_error(s, Z_OK, NULL);
 }
@@ -1033,13 +1142,35 @@ int gzclose_r(gzFile file)
 static int gzwrite_body(gzFile file, const void *buf, unsigned len)                                         /* gzwrite.c:165-243 */
 {
     GzFile *s = gz(file);
-    if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return 0;
-    if ((int)len < 0) { set_error(s, Z_DATA_ERROR, "requested length does not fit in int"); return 0; }
+    if (s == NULL || s->mode != GZ_WRITE) return 0;
+    if (idle(s) && s->err != Z_OK) return 0;            /* (an error of a job that is still out shows once it is done) */
+    if ((int)len < 0) { (void)settle(s); set_error(s, Z_DATA_ERROR, "requested length does not fit in int"); return 0; }
     if (len == 0) return 0;
     if (s->size == 0 && winit(s) == -1) return 0;
-    if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return 0; }
+    if (s->seek) { s->seek = 0; if (settle(s) == -1 || zeros(s, s->skip) == -1) return 0; }
     z_stream &z = s->strm;
     const unsigned put = len;
+    if (s->carry_cap && !s->direct && len < s->carry_cap && (behind(s) || len >= (s->carry_cap >> 2 < (1u << 20) ? s->carry_cap >> 2 : (1u << 20)))) {
+        /* collected for the thread behind: what the small buffer holds is older and goes in first */
+        if (!s->carry[s->cur]) s->carry[s->cur] = (unsigned char *)malloc(s->carry_cap);
+        if (s->carry[s->cur]) {
+            if (!behind(s) && z.avail_in) {
+                memcpy(s->carry[s->cur], z.next_in, z.avail_in);
+                s->carry_n[s->cur] = z.avail_in; z.avail_in = 0;
+            }
+            while (len) {
+                const int k = s->cur;
+                size_t copy = s->carry_cap - s->carry_n[k];
+                if (copy > len) copy = len;
+                memcpy(s->carry[k] + s->carry_n[k], buf, copy);
+                s->carry_n[k] += copy; s->x.pos += copy;
+                buf = (const char *)buf + copy; len -= (unsigned)copy;
+                if (s->carry_n[k] == s->carry_cap && submit(s) == -1) return 0;
+            }
+            return (int)put;
+        }
+    }
+    if (behind(s) && settle(s) == -1) return 0;
     if (len < s->size) {                                /* collect small writes in the input buffer */
         do {
             if (z.avail_in == 0) z.next_in = s->in.data();
@@ -1068,7 +1199,7 @@ int gzwrite(gzFile file, const void *buf, unsigned len)
 int gzputc(gzFile file, int c)                                                                  /* gzwrite.c:246-291 */
 {
     GzFile *s = gz(file);
-    if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return -1;
+    if (s == NULL || s->mode != GZ_WRITE) return -1;
     unsigned char b = (unsigned char)c;
     return gzwrite(file, &b, 1) != 1 ? -1 : (c & 0xff);
 }
@@ -1083,7 +1214,9 @@ int gzputs(gzFile file, const char *str)                                        
 static int gzvprintf_body(gzFile file, const char *format, va_list va)                                      /* gzwrite.c:311-373 */
 {
     GzFile *s = gz(file);
-    if (s == NULL || s->mode != GZ_WRITE || s->err != Z_OK) return 0;
+    if (s == NULL || s->mode != GZ_WRITE) return 0;
+    (void)settle(s);
+    if (s->err != Z_OK) return 0;
     if (s->size == 0 && winit(s) == -1) return 0;
     if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return 0; }
     z_stream &z = s->strm;
@@ -1115,7 +1248,9 @@ static int gzflush_body(gzFile file, int flush)                                 
 {
     GzFile *s = gz(file);
     if (s == NULL) return -1;
-    if (s->mode != GZ_WRITE || s->err != Z_OK) return Z_STREAM_ERROR;
+    if (s->mode != GZ_WRITE) return Z_STREAM_ERROR;
+    (void)settle(s);
+    if (s->err != Z_OK) return Z_STREAM_ERROR;
     if (flush < 0 || flush > Z_FINISH) return Z_STREAM_ERROR;
     if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return -1; }
     comp(s, flush);
@@ -1131,7 +1266,9 @@ static int gzsetparams_body(gzFile file, int level, int strategy)               
 {
     GzFile *s = gz(file);
     if (s == NULL) return Z_STREAM_ERROR;
-    if (s->mode != GZ_WRITE || s->err != Z_OK) return Z_STREAM_ERROR;
+    if (s->mode != GZ_WRITE) return Z_STREAM_ERROR;
+    (void)settle(s);
+    if (s->err != Z_OK) return Z_STREAM_ERROR;
     if (level == s->level && strategy == s->strategy) return Z_OK;
     if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return -1; }
     if (s->size) {
@@ -1153,6 +1290,8 @@ static int gzclose_w_body(gzFile file)                                          
     if (s == NULL) return Z_STREAM_ERROR;
     if (s->mode != GZ_WRITE) return Z_STREAM_ERROR;
     int ret = Z_OK;
+    if (settle(s) == -1) ret = s->err;
+    stop_worker(s);
     if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) ret = s->err; }
     if (comp(s, Z_FINISH) == -1) ret = s->err;
     if (ret == Z_OK && s->want_index && !s->direct && s->members == 1 && !s->index.empty() && write_index(s) == -1) ret = s->err;

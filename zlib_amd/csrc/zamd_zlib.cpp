@@ -994,6 +994,7 @@ int zamd_deflate_index_splits(z_streamp strm, const unsigned long long **recs, u
     return Z_OK;
 }
 unsigned zamd_deflate_chunk_bytes(z_streamp strm) { DState *s = dstate(strm); return s ? s->chunk_size : 0u; }
+unsigned long long zamd_deflate_batch_bytes(z_streamp strm) { DState *s = dstate(strm); return s ? s->batch_bytes : 0ull; }
 int zamd_deflate_index_get(z_streamp strm, const unsigned **pairs, unsigned *n_chunks) {
     DState *s = dstate(strm);
     if (!s || pairs == Z_NULL || n_chunks == Z_NULL) return Z_STREAM_ERROR;
