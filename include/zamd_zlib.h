@@ -232,6 +232,11 @@ unsigned zamd_deflate_chunk_bytes(z_streamp strm);          /* the chunk size of
  * buffered in front, is compressed where it lies.  No counterpart in the reference (deflate.c:1409-1413 sizes the
  * reference's own unit of work, the window). */
 unsigned long long zamd_deflate_batch_bytes(z_streamp strm);
+/* Sets up the GPU engine now, on the calling thread, instead of at the first call that compresses or inflates (Z_OK, or
+ * what that call would have reported).  For callers that want the seconds of set-up outside their own timing, and for
+ * the gz layer, whose helper threads must not be the ones that initialise the GPU runtime (what that runtime registers
+ * for the end of the process has to be registered before the layer's own hook).  No counterpart in the reference. */
+int zamd_z_engine_ready(void);
 unsigned long long zamd_inflate_hinted_chunks(z_streamp strm);   /* chunks inflate() has placed by their index entries so far */
 /* Random access (the reference keeps such access points in memory while it inflates a file once, examples/zran.c:67-72,
  * 249-349): a file written with a 'W' in the mode string (or ZAMD_GZ_WINDOWS=n in the environment: every n-th chunk) also

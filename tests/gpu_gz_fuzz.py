@@ -10,6 +10,7 @@ import tempfile
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["ZAMD_GZ_AHEAD_AFTER_KIB"] = "1024"       # (read once, when the library loads)
 import _zapi as Z
 import zlib_amd
 
@@ -25,12 +26,13 @@ for case in range(cases):
     os.environ["ZAMD_Z_BATCH_MIB"] = str(rng.choice([1, 2, 512]))
     os.environ["ZAMD_GZ_BUF_MIB"] = rng.choice(["1", "32"])       # (1 MiB with batches of 2: writes collected behind the caller fill their buffers)
     os.environ["ZAMD_GZ_BEHIND"] = rng.choice(["1", "1", "0"])
+    os.environ["ZAMD_GZ_AHEAD_MIB"] = rng.choice(["3", "5", "256", "0"])  # (with the small buffer and AHEAD_AFTER below: readers get their data inflated ahead)
     n = rng.choice([rng.randrange(1, len(pool)), rng.randrange(1, 20) << 20, 1, 100])
     off = rng.randrange(0, len(pool) - n + 1)
     data = pool[off:off + n]
     mode = rng.choice(["wb", "wb6I", "wb6W", "wb1W", "wb9I"])
     path = os.path.join(tmp, "f%d.gz" % case).encode()
-    desc = dict(case=case, n=n, chunk=chunk, mode=mode, batch=os.environ["ZAMD_Z_BATCH_MIB"], buf=os.environ["ZAMD_GZ_BUF_MIB"], behind=os.environ["ZAMD_GZ_BEHIND"])
+    desc = dict(case=case, n=n, chunk=chunk, mode=mode, batch=os.environ["ZAMD_Z_BATCH_MIB"], buf=os.environ["ZAMD_GZ_BUF_MIB"], behind=os.environ["ZAMD_GZ_BEHIND"], ahead=os.environ["ZAMD_GZ_AHEAD_MIB"])
     g = l.gzopen(path, mode.encode())
     assert g
     at = 0
@@ -65,6 +67,14 @@ for case in range(cases):
     buf = C.create_string_buffer(9 << 20)
     while True:
         k = rng.choice([1, 4096, rng.randrange(1, 1 << 20), rng.randrange(1, 9 << 20)])
+        if got and rng.random() < 0.05:                 # push the last byte back and read it again
+            assert l.gzungetc(got[-1], g) == got[-1], desc
+            del got[-1]
+        if rng.random() < 0.03:
+            c = l.gzgetc(g)
+            if c >= 0:
+                got.append(c)
+            l.gzoffset(g), l.gzeof(g), l.gzdirect(g)
         r = l.gzread(g, buf, k)
         if r < 0:
             ok = False

@@ -304,6 +304,80 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
 
 
+def test_reading_ahead_of_the_caller_gives_the_same_bytes(tmp_path):
+    """A reader that takes its data in small requests gets it inflated ahead, several buffers' worth at a time, by a
+    thread of the file's own.  What gzread, gzgetc, gzungetc, gzgets, gzseek, gzrewind and gzeof hand out must not depend
+    on it (gzread.c:288-544, gzlib.c:339-436): the same calls with ZAMD_GZ_AHEAD_MIB=0 give the same results, also on a
+    file of two members, on one cut short (Z_BUF_ERROR behind everything that could be inflated, gzread.c:196-200) and on
+    a damaged one (Z_DATA_ERROR in the end; the same bytes up to there either way).  (A child process: sizes come from the environment.)"""
+    script = r'''
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ["ZAMD_Z_CHUNK"] = "262144"
+os.environ["ZAMD_GZ_BUF_MIB"] = "1"
+os.environ["ZAMD_GZ_AHEAD_AFTER_KIB"] = "1024"
+import _zapi as Z
+import zlib_amd
+l = Z.lib()
+data = bytes(zlib_amd.corpus(30 << 20, 4, 32)).replace(b"\n", b" ")
+data = data[:9 << 20] + b"\n" + data[(9 << 20) + 1:]
+tmp = sys.argv[1]
+def path(name): return os.path.join(tmp, name).encode()
+g = l.gzopen(path("a.gz"), b"wb6I"); assert l.gzwrite(g, data, len(data)) == len(data); assert l.gzclose(g) == 0
+g = l.gzopen(path("two.gz"), b"wb6"); assert l.gzwrite(g, data[:20 << 20], 20 << 20) == 20 << 20; assert l.gzclose(g) == 0
+g = l.gzopen(path("two.gz"), b"ab1"); assert l.gzwrite(g, data[20 << 20:], 10 << 20) == 10 << 20; assert l.gzclose(g) == 0
+raw = open(path("a.gz"), "rb").read()
+open(path("cut.gz"), "wb").write(raw[:len(raw) * 6 // 10])
+bad = bytearray(raw); bad[len(raw) // 2] ^= 0x55
+open(path("bad.gz"), "wb").write(bytes(bad))
+buf = C.create_string_buffer(1 << 20)
+def session(name, ahead, whole):
+    os.environ["ZAMD_GZ_AHEAD_MIB"] = ahead
+    log = []
+    g = l.gzopen(path(name), b"rb")
+    out = bytearray()
+    for k in ([300000] * 30 + [1, 70000, 999999] * 8) * (1 if whole else 4):     # (a file that is not whole: until it fails)
+        r = l.gzread(g, buf, k); log.append(r)
+        if r <= 0: break
+        out += buf.raw[:r]
+        if len(out) %% 7 == 0:
+            assert l.gzungetc(out[-1], g) == out[-1]; del out[-1]
+        if len(out) %% 5 == 0:
+            c = l.gzgetc(g); log.append(c)
+            if c >= 0: out.append(c)
+        assert l.gztell(g) == len(out)
+    err = C.c_int(0); l.gzerror(g, C.byref(err)); log.append(err.value)
+    if whole:
+        assert err.value == 0
+        line = C.create_string_buffer(200)
+        log.append(l.gzgets(g, line, 200)); out += line.value
+        at = l.gzseek(g, 5 << 20, 1); log.append(at)              # forward, over what may have been inflated ahead
+        r = l.gzread(g, buf, 1000); log.append(buf.raw[:r]); assert buf.raw[:r] == data[at:at + r]
+        assert l.gzseek(g, 1000, 0) == 1000                        # back: from the start again
+        r = l.gzread(g, buf, 100); assert buf.raw[:r] == data[1000:1100]
+        assert l.gzseek(g, len(data) - 10, 0) == len(data) - 10
+        r = l.gzread(g, buf, 100); log.append(r); log.append(l.gzeof(g)); assert buf.raw[:r] == data[-10:]
+        assert l.gzrewind(g) == 0
+        r = l.gzread(g, buf, 100); assert buf.raw[:r] == data[:100]
+    log.append(l.gzclose(g))
+    return bytes(out), log
+for name in ("a.gz", "two.gz", "cut.gz", "bad.gz"):
+    whole = name in ("a.gz", "two.gz")
+    a, la = session(name, "4", whole)
+    b, lb = session(name, "0", whole)
+    if name != "bad.gz":
+        assert data.startswith(a[:len(a) - 200]) and a == b and la == lb, (name, len(a), len(b), la[-8:], lb[-8:])
+    else:       # (what a flipped byte does to the data behind it shows at the latest in the check value; both ways see the same bytes)
+        m = min(len(a), len(b))
+        assert m > 10 << 20 and a[:10 << 20] == data[:10 << 20] and a[:m] == b[:m], (len(a), len(b))
+    if name == "cut.gz": assert la[-2] == Z.Z_BUF_ERROR and la[-1] == Z.Z_BUF_ERROR, la[-4:]
+    if name == "bad.gz": assert la[-2] == Z.Z_DATA_ERROR and lb[-2] == Z.Z_DATA_ERROR, (la[-4:], lb[-4:])
+print("ok")
+''' % ROOT
+    r = subprocess.run([os.sys.executable, "-c", script, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr
+
+
 def test_gzseek_starts_from_the_window_in_front_of_the_chunk(tmp_path):
     """A file written with 'W' stores the 32 KiB in front of every chunk beside the index (what examples/zran.c:67-72 keeps
     in memory): gzseek to any offset then inflates one chunk, not the file from its start.  256 MiB, 20 random offsets,

@@ -101,14 +101,32 @@ struct GzFile {
     bool behind_job;                      /* a job is out and has not been waited for */
     std::thread worker; bool worker_on;
     std::mutex wmu; std::condition_variable wcv;
-    const unsigned char *job_p; size_t job_n; bool job_ready, job_done, wquit;   /* under wmu */
+    const unsigned char *job_p; size_t job_n; bool job_ready, job_done, job_out, wquit;   /* under wmu; job_out: handed over and not finished */
+    /* Reading ahead of the caller: a reader that has taken AHEAD_AFTER bytes in small requests gets its data inflated
+     * ahead_bytes at a time (a round of that size runs at several times the speed of one buffer's worth) by the same
+     * kind of thread, into one of two buffers, while it copies from the other.  While a job is out, strm, in, fill, eof,
+     * how and the limits belong to the thread; it leaves its result in ra_n / ra_rc / ra_err / ra_msg and touches
+     * neither x nor err / msg (the gzgetc() macro of zlib.h reads x without a call).  `ra_out`: a job has been started
+     * and its result is not taken yet; the caller's side takes it when x.have reaches 0. */
+    std::vector<unsigned char, NoInitAlloc<unsigned char> > ra_buf[2];
+    unsigned ahead_bytes; uint64_t seq;   /* 0: never; bytes handed out through the buffer since the last positioning */
+    bool ra_out; int ra_k, ra_cur;        /* the job's buffer; the buffer x.next points into (-1: the ordinary one) */
+    unsigned ra_n; int ra_rc, ra_err; std::string ra_msg;
 };
+thread_local bool t_ahead = false;        /* this thread is a file's read-ahead thread */
 
 inline GzFile *gz(gzFile f) { return (GzFile *)f; }
-inline bool fatal(const GzFile *s) { return s->err != Z_OK && s->err != Z_BUF_ERROR; }
+inline bool fatal(const GzFile *s) { const int e = t_ahead ? s->ra_err : s->err; return e != Z_OK && e != Z_BUF_ERROR; }
 
 void set_error(GzFile *s, int err, const char *msg)      /* gz_error, gzlib.c:575-615 */
 {
+    if (t_ahead) {                                      /* an error ahead of the caller: it shows when the caller gets there */
+        s->ra_err = err;
+        if (msg == NULL) s->ra_msg.clear();
+        else if (err == Z_MEM_ERROR) s->ra_msg = "out of memory";
+        else s->ra_msg = s->path + ": " + msg;
+        return;
+    }
     if (err != Z_OK && err != Z_BUF_ERROR) s->x.have = 0;
     s->err = err;
     if (msg == NULL) s->msg.clear();
@@ -116,11 +134,16 @@ void set_error(GzFile *s, int err, const char *msg)      /* gz_error, gzlib.c:57
     else s->msg = s->path + ": " + msg;
 }
 
+void wait_idle(GzFile *s);
+int ahead_start(GzFile *s);
+int ahead_take(GzFile *s, bool more);
+
 void reset(GzFile *s)                                    /* gz_reset, gzlib.c:75-88 */
 {
     s->x.have = 0;
     if (s->mode == GZ_READ) { s->eof = 0; s->past = 0; s->how = LOOK; s->skip_trailer = 0; s->read_limit = 0; s->out_limit = 0; }
     s->seek = 0;
+    s->ra_out = false; s->ra_cur = -1; s->seq = 0;      /* (the caller has waited for a job that was out) */
     set_error(s, Z_OK, NULL);
     s->x.pos = 0;
     s->strm.avail_in = 0;
@@ -148,7 +171,9 @@ static gzFile open_file_body(const char *path, int fd, const char *mode)      /*
     s->want_index = 0; s->members = 0; s->base = s->produced = s->member_at = s->index_member = 0; s->have_ridx = 0; s->ridx_member = 0; s->isplits_per = 0; s->rsplits_per = 0;
     s->win_every = 0; s->chunk_bytes = 0; s->upos = 0;
     s->carry[0] = s->carry[1] = NULL; s->carry_n[0] = s->carry_n[1] = 0; s->carry_cap = 0; s->cur = 0; s->behind_job = false;
-    s->worker_on = false; s->job_p = NULL; s->job_n = 0; s->job_ready = s->job_done = s->wquit = false;
+    s->worker_on = false; s->job_p = NULL; s->job_n = 0; s->job_ready = s->job_done = s->job_out = s->wquit = false;
+    s->ra_out = false; s->ra_k = 0; s->ra_cur = -1; s->ra_n = 0; s->ra_rc = 0; s->ra_err = Z_OK; s->seq = 0;
+    { const char *v = getenv("ZAMD_GZ_AHEAD_MIB"); unsigned long m = v ? strtoul(v, NULL, 10) : 256; s->ahead_bytes = (unsigned)((m > 1024 ? 1024 : m) << 20); }
     s->ridx_woff = 0; s->ridx_wevery = s->ridx_nwin = 0; s->data_start = 0; s->raw_mode = 0; s->skip_trailer = 0; s->read_limit = 0; s->out_limit = 0; s->window_seeks = 0;
     { const char *v = getenv("ZAMD_GZ_INDEX"); if (v && *v && *v != '0') s->want_index = 1; }
     { const char *v = getenv("ZAMD_GZ_WINDOWS"); if (v && atoi(v) > 0) { s->win_every = (unsigned)atoi(v); s->want_index = 1; } }
@@ -299,11 +324,14 @@ int look(GzFile *s)                                     /* gz_look, gzread.c:86-
         z.avail_in = 0; s->eof = 1; s->x.have = 0;
         return 0;
     }
-    s->x.next = s->out.data();                          /* not gzip at all: hand the bytes through */
+    s->x.next = s->out.data(); s->ra_cur = -1;          /* not gzip at all: hand the bytes through */
     if (z.avail_in) { memcpy(s->x.next, z.next_in, z.avail_in); s->x.have = z.avail_in; z.avail_in = 0; }
     s->how = COPY; s->direct = 1;
     return 0;
 }
+
+const uint64_t AHEAD_AFTER = [] { const char *v = getenv("ZAMD_GZ_AHEAD_AFTER_KIB"); return (v ? strtoull(v, NULL, 10) : 65536ull) << 10; }();
+const unsigned AHEAD_PAD = 64;                          /* room in front of a buffer's data for gzungetc() */
 
 int decomp(GzFile *s)                                   /* gz_decomp, gzread.c:172-218 */
 {
@@ -328,15 +356,57 @@ int decomp(GzFile *s)                                   /* gz_decomp, gzread.c:1
         if (ret == Z_MEM_ERROR) { set_error(s, Z_MEM_ERROR, "out of memory"); return -1; }
         if (ret == Z_DATA_ERROR) { set_error(s, Z_DATA_ERROR, z.msg == NULL ? "compressed data error" : z.msg); return -1; }
     } while (z.avail_out && ret != Z_STREAM_END);
-    s->x.have = had - z.avail_out;
-    s->x.next = z.next_out - s->x.have;
+    if (t_ahead) s->ra_n = had - z.avail_out;
+    else { s->x.have = had - z.avail_out; s->x.next = z.next_out - s->x.have; }
     if (ret == Z_STREAM_END) { s->how = LOOK; if (s->raw_mode) s->skip_trailer = 8; }   /* another member may follow */
     return 0;
 }
 
-int fetch(GzFile *s)                                    /* gz_fetch, gzread.c:226-253 */
+/* inflate() of this library runs at what one call holds: a request of hundreds of megabytes gets input to match (about
+ * what it inflates from, the request's own size at most), not one buffer at a time.  Sets s->fill for the decomp() that
+ * follows (the caller clears it). */
+void size_input(GzFile *s, unsigned len)
 {
     z_stream &z = s->strm;
+    static const uint64_t big_cap = [] { const char *v = getenv("ZAMD_GZ_READ_MIB"); uint64_t m = v ? strtoull(v, nullptr, 10) : 1024; return (m > 2047 ? 2047 : m) << 20; }();
+    /* how much input the request inflates from: by the chunk index when the file has one (inflate() then places
+     * exactly those chunks, straight into the caller's memory), else by what the data has compressed to so far.
+     * Input beyond the request would be inflated ahead into a buffer of inflate()'s own and copied from there. */
+    uint64_t want_in = len;
+    const uint64_t done = zamd_inflate_hinted_chunks(&z);
+    if (s->have_ridx && s->hinting && done < s->ridx.size() / 2) {
+        uint64_t comp = 0, raw = 0;
+        for (size_t k = (size_t)done; k < s->ridx.size() / 2 && raw < len; k++) { comp += s->ridx[2 * k]; raw += s->ridx[2 * k + 1]; }
+        want_in = comp + 64;
+    } else if (z.total_in > (1u << 20) && z.total_out > z.total_in) {
+        want_in = (uint64_t)((double)len * ((double)z.total_in / (double)z.total_out) * 1.02) + 65536;
+    }
+    if (want_in > big_cap) want_in = big_cap;
+    if (want_in > s->size && big_cap) {
+        if (s->in.size() < want_in) {
+            /* a new buffer with some room to spare (the next request's chunks may be a little larger); only the
+             * bytes still waiting move over */
+            uint64_t cap = want_in + (want_in >> 3);
+            if (cap > big_cap) cap = big_cap;
+            try {
+                std::vector<unsigned char, NoInitAlloc<unsigned char> > bigger((size_t)cap);
+                if (z.avail_in) memcpy(bigger.data(), z.next_in, z.avail_in);
+                s->in.swap(bigger);
+                z.next_in = s->in.data();
+            } catch (...) { want_in = s->in.size(); }
+        }
+        s->fill = (unsigned)want_in;
+    }
+}
+
+/* `more`: the caller reads in small requests, so reading ahead of it pays */
+int fetch(GzFile *s, bool more = true)                  /* gz_fetch, gzread.c:226-253 */
+{
+    z_stream &z = s->strm;
+    if (s->ra_out) {                                    /* what the thread has inflated ahead comes first */
+        if (ahead_take(s, more) == -1) return -1;
+        if (s->x.have) return 0;
+    }
     do {
         switch (s->how) {
         case LOOK:
@@ -348,9 +418,14 @@ int fetch(GzFile *s)                                    /* gz_fetch, gzread.c:22
             s->x.next = s->out.data();
             return 0;
         case GZIP:
+            if (more && s->ahead_bytes > (s->size << 1) && s->seq >= AHEAD_AFTER && !s->out_limit && !s->read_limit && s->err == Z_OK && ahead_start(s) == 0) {
+                if (ahead_take(s, true) == -1) return -1;
+                break;
+            }
             z.avail_out = s->size << 1; z.next_out = s->out.data();
             if (s->out_limit) { if (s->out_limit < z.avail_out) z.avail_out = (unsigned)s->out_limit; s->out_limit = 0; }
             if (decomp(s) == -1) return -1;
+            s->ra_cur = -1; s->seq += s->x.have;
         }
     } while (s->x.have == 0 && (!s->eof || z.avail_in));
     return 0;
@@ -366,7 +441,7 @@ int skip_out(GzFile *s, z_off64_t len)                  /* gz_skip, gzread.c:256
         if (s->x.have) {
             unsigned n = (z_off64_t)s->x.have > len ? (unsigned)len : s->x.have;
             s->x.have -= n; s->x.next += n; s->x.pos += n; len -= n;
-        } else if (at_end(s)) break;
+        } else if (!s->ra_out && at_end(s)) break;
         else if (fetch(s) == -1) return -1;
     }
     return 0;
@@ -495,12 +570,67 @@ void worker_loop(GzFile *s)
             if (s->wquit) return;
             s->job_ready = false; p = s->job_p; n = s->job_n;
         }
-        s->strm.next_in = (Bytef *)p; s->strm.avail_in = (uInt)n;
-        try { (void)comp(s, Z_NO_FLUSH); }
-        catch (...) { s->strm.avail_in = 0; set_error(s, Z_MEM_ERROR, "out of memory"); }
-        { std::lock_guard<std::mutex> g(s->wmu); s->job_done = true; }
+        if (s->mode == GZ_READ) {
+            /* ahead_bytes more of the inflated data into the job's buffer, the way a large gzread() gets them */
+            t_ahead = true;
+            s->ra_n = 0; s->ra_err = Z_OK; s->ra_msg.clear();
+            try {
+                /* With the chunk index the request ends where a chunk ends: what inflate() still holds of the chunks it
+                 * has placed, and whole chunks behind that.  A request that ends inside a chunk costs a round of its own
+                 * for that one chunk (some 9 ms), and so does every request after it. */
+                unsigned len = s->ahead_bytes;
+                z_stream &z = s->strm;
+                const uint64_t done = zamd_inflate_hinted_chunks(&z);
+                if (s->have_ridx && s->hinting && !s->raw_mode && done < s->ridx.size() / 2) {
+                    uint64_t placed = 0;
+                    for (size_t k = 0; k < (size_t)done; k++) placed += s->ridx[2 * k + 1];
+                    if (placed >= z.total_out && placed - z.total_out < len) {
+                        uint64_t acc = placed - z.total_out;
+                        for (size_t k = (size_t)done; k < s->ridx.size() / 2 && acc + s->ridx[2 * k + 1] <= s->ahead_bytes; k++) acc += s->ridx[2 * k + 1];
+                        if (acc) len = (unsigned)acc;
+                    }
+                }
+                size_input(s, len);
+                s->strm.avail_out = len; s->strm.next_out = s->ra_buf[s->ra_k].data() + AHEAD_PAD;
+                s->ra_rc = decomp(s);
+            } catch (...) { s->ra_rc = -1; s->ra_n = 0; s->ra_err = Z_MEM_ERROR; s->ra_msg = "out of memory"; }
+            s->fill = 0;
+        } else {
+            s->strm.next_in = (Bytef *)p; s->strm.avail_in = (uInt)n;
+            try { (void)comp(s, Z_NO_FLUSH); }
+            catch (...) { s->strm.avail_in = 0; set_error(s, Z_MEM_ERROR, "out of memory"); }
+        }
+        { std::lock_guard<std::mutex> g(s->wmu); s->job_done = true; s->job_out = false; }
         s->wcv.notify_all();
     }
+}
+/* A process that ends with such files still open (exit() without gzclose()) must not take the GPU runtime down under a
+ * job that is still running: the files that have a thread are listed, and exit() waits for their jobs. */
+std::mutex g_files_mu;
+std::vector<GzFile *> g_files;
+void wait_at_exit()
+{
+    const bool trace = getenv("ZAMD_Z_TRACE") != nullptr;
+    std::lock_guard<std::mutex> l(g_files_mu);
+    for (GzFile *s : g_files) {
+        std::unique_lock<std::mutex> g(s->wmu);
+        if (trace) fprintf(stderr, "zamd_gz exit: %s has a job out: %d\n", s->path.c_str(), (int)s->job_out);
+        s->wcv.wait(g, [&] { return !s->job_out; });
+        if (trace) fprintf(stderr, "zamd_gz exit: %s is idle\n", s->path.c_str());
+    }
+}
+void start_worker(GzFile *s)                            /* throws what std::thread and the list throw */
+{
+    /* the GPU runtime is set up first, on this thread: what it registers for the end of the process then runs after
+     * the hook below (handlers run in the reverse order), not under a job that is still using it */
+    if (zamd_z_engine_ready() != Z_OK) throw std::bad_alloc();
+    std::lock_guard<std::mutex> l(g_files_mu);
+    static const bool hooked = atexit(wait_at_exit) == 0;
+    (void)hooked;
+    g_files.push_back(s);
+    try { s->worker = std::thread(worker_loop, s); }
+    catch (...) { g_files.pop_back(); throw; }
+    s->worker_on = true;
 }
 /* After this the file's state is the caller's to read again. */
 void wait_idle(GzFile *s)
@@ -531,7 +661,7 @@ int submit(GzFile *s)
     if (s->err != Z_OK) return -1;
     if (n == 0) return 0;
     if (!s->worker_on) {
-        try { s->worker = std::thread(worker_loop, s); s->worker_on = true; }
+        try { start_worker(s); }
         catch (...) { s->worker_on = false; }
     }
     if (!s->worker_on || !s->carry[k ^ 1]) {
@@ -542,7 +672,7 @@ int submit(GzFile *s)
             return comp(s, Z_NO_FLUSH);
         }
     }
-    { std::lock_guard<std::mutex> g(s->wmu); s->job_p = s->carry[k]; s->job_n = n; s->job_ready = true; s->job_done = false; }
+    { std::lock_guard<std::mutex> g(s->wmu); s->job_p = s->carry[k]; s->job_n = n; s->job_ready = true; s->job_done = false; s->job_out = true; }
     s->behind_job = true;
     s->wcv.notify_all();
     s->cur = k ^ 1;
@@ -556,6 +686,38 @@ int settle(GzFile *s)
     wait_idle(s);
     return rc == -1 || s->err != Z_OK ? -1 : 0;
 }
+/* Reading: start a job into the buffer the caller is not copying from.  The file must be idle.  -1: no thread or no
+ * memory to be had (the caller reads on the ordinary way). */
+int ahead_start(GzFile *s)
+{
+    const int k = s->ra_cur == 0 ? 1 : 0;
+    try {
+        if (s->ra_buf[k].size() < (size_t)s->ahead_bytes + AHEAD_PAD) s->ra_buf[k].resize((size_t)s->ahead_bytes + AHEAD_PAD);
+        if (!s->worker_on) start_worker(s);
+    } catch (...) { return -1; }
+    s->ra_k = k;
+    { std::lock_guard<std::mutex> g(s->wmu); s->job_ready = true; s->job_done = false; s->job_out = true; }
+    s->behind_job = true; s->ra_out = true;
+    s->wcv.notify_all();
+    return 0;
+}
+/* Take the job's result (waiting for it if need be): its bytes become what the caller reads next, its error the
+ * file's.  `more`: the next job starts right away.  -1: the job failed. */
+int ahead_take(GzFile *s, bool more)
+{
+    wait_idle(s);
+    s->ra_out = false;
+    if (s->ra_err != Z_OK) {
+        s->err = s->ra_err; s->msg = s->ra_msg;
+        if (fatal(s)) s->x.have = 0;
+    }
+    if (s->ra_rc == -1) return -1;
+    s->x.next = s->ra_buf[s->ra_k].data() + AHEAD_PAD; s->x.have = s->ra_n; s->ra_cur = s->ra_k;
+    s->seq += s->ra_n;
+    if (more && s->ra_n && s->how == GZIP && s->err == Z_OK) (void)ahead_start(s);
+    return 0;
+}
+
 void stop_worker(GzFile *s)
 {
     wait_idle(s);
@@ -564,6 +726,8 @@ void stop_worker(GzFile *s)
         s->wcv.notify_all();
         s->worker.join();
         s->worker_on = false;
+        std::lock_guard<std::mutex> l(g_files_mu);
+        for (size_t i = 0; i < g_files.size(); i++) if (g_files[i] == s) { g_files.erase(g_files.begin() + i); break; }
     }
     free(s->carry[0]); free(s->carry[1]);
     s->carry[0] = s->carry[1] = NULL; s->carry_n[0] = s->carry_n[1] = 0;
@@ -707,7 +871,7 @@ int window_seek(GzFile *s, z_off64_t target)
     const size_t a = c / s->ridx_wevery * s->ridx_wevery;          /* the chunk with a window in front of it, at or before c */
     if (a == 0 || a / s->ridx_wevery - 1 >= s->ridx_nwin) return 0;
     /* not worth it when the data in between is about to be inflated anyway */
-    if (target >= s->x.pos && (uint64_t)a * chunk0 <= (uint64_t)s->x.pos + s->x.have) return 0;
+    if (target >= s->x.pos && (uint64_t)a * chunk0 <= (uint64_t)s->x.pos + s->x.have + (s->ra_out ? s->ra_n : 0u)) return 0;
     if (s->size == 0 && look(s) == -1) return -1;                  /* buffers and the inflate state */
     unsigned char wh[24];
     std::vector<unsigned char> win(32768);
@@ -731,6 +895,7 @@ int window_seek(GzFile *s, z_off64_t target)
     if (s->rsplits_per) (void)zamd_inflate_index_hint_splits(&z, s->rsplits.data() + a * (size_t)s->rsplits_per, s->rsplits_per);
     z.avail_in = 0; z.next_in = s->in.data();
     s->x.have = 0; s->eof = 0; s->past = 0; s->seek = 0; s->skip_trailer = 0;
+    s->ra_out = false; s->ra_cur = -1; s->seq = 0;                 /* what was inflated ahead is dropped */
     set_error(s, Z_OK, NULL);
     s->how = GZIP; s->direct = 0; s->raw_mode = 1;
     s->read_limit = need;                                          /* the first read brings just the chunks up to the target's */
@@ -828,6 +993,7 @@ int zamd_gz_seek_stats(gzFile file, unsigned long long *chunks_decoded, unsigned
 {
     GzFile *s = gz(file);
     if (s == NULL || s->mode != GZ_READ) return -1;
+    wait_idle(s);
     if (chunks_decoded) *chunks_decoded = s->size ? zamd_inflate_hinted_chunks(&s->strm) : 0ull;
     if (window_seeks) *window_seeks = s->window_seeks;
     return 0;
@@ -858,7 +1024,9 @@ int gzbuffer(gzFile file, unsigned size)                                        
 int gzrewind(gzFile file)                                                                       /* gzlib.c:339-359 */
 {
     GzFile *s = gz(file);
-    if (s == NULL || s->mode != GZ_READ || fatal(s)) return -1;
+    if (s == NULL || s->mode != GZ_READ) return -1;
+    wait_idle(s);
+    if (fatal(s)) return -1;
     if (lseek(s->fd, s->start, SEEK_SET) == -1) return -1;
     reset(s);
     return 0;
@@ -869,6 +1037,7 @@ static z_off64_t gzseek64_body(gzFile file, z_off64_t offset, int whence)       
     GzFile *s = gz(file);
     if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return -1;
     if (s->mode == GZ_WRITE) (void)settle(s);
+    else wait_idle(s);
     if (fatal(s)) return -1;
     if (whence != SEEK_SET && whence != SEEK_CUR) return -1;
     if (whence == SEEK_SET) offset -= s->x.pos;
@@ -930,7 +1099,7 @@ z_off64_t gzoffset64(gzFile file)                                               
 {
     GzFile *s = gz(file);
     if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return -1;
-    if (s->mode == GZ_WRITE) wait_idle(s);              /* (what is collected and not yet compressed is in no file) */
+    wait_idle(s);                                       /* (what is collected and not yet compressed is in no file) */
     z_off64_t off = lseek(s->fd, 0, SEEK_CUR);
     if (off == -1) return -1;
     if (s->mode == GZ_READ) off -= s->strm.avail_in;
@@ -958,12 +1127,19 @@ void gzclearerr(gzFile file)                                                    
 {
     GzFile *s = gz(file);
     if (s == NULL || (s->mode != GZ_READ && s->mode != GZ_WRITE)) return;
-    if (s->mode == GZ_WRITE) wait_idle(s);
+    wait_idle(s);
     if (s->mode == GZ_READ) { s->eof = 0; s->past = 0; }
     set_error(s, Z_OK, NULL);
 }
 
 /* ------------------------------------------------------------------ gzread.c */
+/* Requests that go through the buffers: those below two buffers' worth, and, once the reader has shown that it reads on
+ * and on, those that are small beside what the read-ahead thread inflates at a time (one round of that size is faster
+ * than four of a quarter). */
+static inline bool small(const GzFile *s, unsigned len)
+{
+    return len < (s->size << 1) || (s->ahead_bytes > (s->size << 1) && len <= s->ahead_bytes / 4 && s->seq >= AHEAD_AFTER);
+}
 static int gzread_body(gzFile file, voidp buf, unsigned len)                                                /* gzread.c:288-379 */
 {
     GzFile *s = gz(file);
@@ -978,12 +1154,15 @@ static int gzread_body(gzFile file, voidp buf, unsigned len)                    
             n = s->x.have > len ? len : s->x.have;
             memcpy(buf, s->x.next, n);
             s->x.next += n; s->x.have -= n;
+        } else if (s->ra_out) {                         /* what was inflated ahead comes first, whatever the request's size */
+            if (ahead_take(s, small(s, len)) == -1) return -1;
+            continue;
         } else if (at_end(s)) { s->past = 1; break; }
         else if (s->how == LOOK && len >= ((s->size ? s->size : s->want) << 1)) {      /* a large request at a member's start: find out what follows, */
             if (look(s) == -1) return -1;                                  /* then straight into the caller's memory as well */
             if (s->how == LOOK && s->x.have == 0 && s->strm.avail_in == 0 && s->eof) { s->past = 1; break; }
             continue;
-        } else if (s->how == LOOK || len < (s->size << 1)) {      /* small request or new member: through the buffer */
+        } else if (s->how == LOOK || small(s, len)) {   /* small request or new member: through the buffer */
             if (fetch(s) == -1) return -1;
             continue;
         } else if (s->how == COPY) {                            /* large request: straight into the caller's memory */
@@ -992,40 +1171,13 @@ static int gzread_body(gzFile file, voidp buf, unsigned len)                    
             /* inflate() of this library runs at what one call holds: a request of hundreds of megabytes gets input to
              * match (about what it inflates from, the request's own size at most), not one buffer of 32 MiB at a time —
              * that is a round of some seventy chunks, as slow as a round of thousands */
-            static const uint64_t big_cap = [] { const char *v = getenv("ZAMD_GZ_READ_MIB"); uint64_t m = v ? strtoull(v, nullptr, 10) : 1024; return (m > 2047 ? 2047 : m) << 20; }();
-            /* how much input the request inflates from: by the chunk index when the file has one (inflate() then places
-             * exactly those chunks, straight into the caller's memory), else by what the data has compressed to so far.
-             * Input beyond the request would be inflated ahead into a buffer of inflate()'s own and copied from there. */
-            uint64_t want_in = len;
-            const uint64_t done = zamd_inflate_hinted_chunks(&z);
-            if (s->have_ridx && s->hinting && done < s->ridx.size() / 2) {
-                uint64_t comp = 0, raw = 0;
-                for (size_t k = (size_t)done; k < s->ridx.size() / 2 && raw < len; k++) { comp += s->ridx[2 * k]; raw += s->ridx[2 * k + 1]; }
-                want_in = comp + 64;
-            } else if (z.total_in > (1u << 20) && z.total_out > z.total_in) {
-                want_in = (uint64_t)((double)len * ((double)z.total_in / (double)z.total_out) * 1.02) + 65536;
-            }
-            if (want_in > big_cap) want_in = big_cap;
-            if (want_in > s->size && big_cap) {
-                if (s->in.size() < want_in) {
-                    /* a new buffer with some room to spare (the next request's chunks may be a little larger); only the
-                     * bytes still waiting move over */
-                    uint64_t cap = want_in + (want_in >> 3);
-                    if (cap > big_cap) cap = big_cap;
-                    try {
-                        std::vector<unsigned char, NoInitAlloc<unsigned char> > bigger((size_t)cap);
-                        if (z.avail_in) memcpy(bigger.data(), z.next_in, z.avail_in);
-                        s->in.swap(bigger);
-                        z.next_in = s->in.data();
-                    } catch (...) { want_in = s->in.size(); }
-                }
-                s->fill = (unsigned)want_in;
-            }
+            size_input(s, len);
             z.avail_out = len; z.next_out = (Bytef *)buf;
             const int rc = decomp(s);
             s->fill = 0;
             if (rc == -1) return -1;
             n = s->x.have; s->x.have = 0;
+            s->seq += n;
         }
         len -= n; buf = (char *)buf + n; got += n; s->x.pos += n;
     } while (len);
@@ -1065,8 +1217,14 @@ static int gzungetc_body(int c, gzFile file)                                    
     if (s->size == 0 && look(s) == -1) return -1;       /* the buffers must exist before a byte can be parked in them */
     unsigned char *const out = s->out.data();
     const size_t cap = (size_t)s->size << 1;
+    if (s->x.have && s->ra_cur >= 0) {                  /* the data lies in a read-ahead buffer: there is room in front of it */
+        if (s->x.next == s->ra_buf[s->ra_cur].data()) { set_error(s, Z_DATA_ERROR, "out of room to push characters"); return -1; }
+        s->x.have++; s->x.next--; s->x.next[0] = (unsigned char)c;
+        s->x.pos--; s->past = 0;
+        return c;
+    }
     if (s->x.have == 0) {                               /* empty: the byte goes to the very end, room for more in front */
-        s->x.have = 1; s->x.next = out + cap - 1; s->x.next[0] = (unsigned char)c;
+        s->x.have = 1; s->x.next = out + cap - 1; s->x.next[0] = (unsigned char)c; s->ra_cur = -1;
         s->x.pos--; s->past = 0;
         return c;
     }
@@ -1117,7 +1275,8 @@ int gzdirect(gzFile file)                                                       
 {
     GzFile *s = gz(file);
     if (s == NULL) return 0;
-    if (s->mode == GZ_READ && s->how == LOOK && s->x.have == 0) (void)look(s);
+    if (s->mode == GZ_READ) wait_idle(s);
+    if (s->mode == GZ_READ && s->how == LOOK && s->x.have == 0 && !s->ra_out) (void)look(s);
     return s->direct;
 }
 
@@ -1126,6 +1285,7 @@ static int gzclose_r_body(gzFile file)                                          
     GzFile *s = gz(file);
     if (s == NULL) return Z_STREAM_ERROR;
     if (s->mode != GZ_READ) return Z_STREAM_ERROR;
+    stop_worker(s);
     if (s->size) inflateEnd(&s->strm);
     int err = s->err == Z_BUF_ERROR ? Z_BUF_ERROR : Z_OK;
     int ret = close(s->fd);

@@ -994,6 +994,10 @@ int zamd_deflate_index_splits(z_streamp strm, const unsigned long long **recs, u
     return Z_OK;
 }
 unsigned zamd_deflate_chunk_bytes(z_streamp strm) { DState *s = dstate(strm); return s ? s->chunk_size : 0u; }
+int zamd_z_engine_ready(void) {
+    try { LaneLock lk; return engine_locked() ? Z_OK : (g_gpu.rc == ZAMD_MEM_ERROR ? Z_MEM_ERROR : Z_STREAM_ERROR); }
+    catch (...) { return Z_MEM_ERROR; }
+}
 unsigned long long zamd_deflate_batch_bytes(z_streamp strm) { DState *s = dstate(strm); return s ? s->batch_bytes : 0ull; }
 int zamd_deflate_index_get(z_streamp strm, const unsigned **pairs, unsigned *n_chunks) {
     DState *s = dstate(strm);
@@ -1814,6 +1818,11 @@ static int inflate_body(z_streamp strm, int flush) {
                 for (unsigned i = 0; i < nb; i++) s->in.push_back((uint8_t)(v >> (8 * i)));
                 s->bit_off = off; s->prime_bits = 0; s->prime_hold = 0;
             }
+            // No room at all, and the chunk index says that what comes next inflates to something: a round now would only
+            // park a chunk or two in the stream's own buffer (a round of one chunk takes 9 ms, as long as one of a
+            // hundred); the caller's next call, with room, takes them along.  (Without the index the rest may be an
+            // empty last block and the trailer, which must not wait for room: inflate.c:1165-1210 needs none either.)
+            if (strm->avail_out == 0 && s->bit_off == 0 && s->hint_pos + 1 < s->hints.size() && s->hints[s->hint_pos + 1] != 0) break;
             bool tried_all = false;
             if ((s->in.empty() || (s->in.size() < (4u << 20) && strm->avail_in >= (8u << 20) && !s->tail_partial)) && strm->avail_in >= (1u << 20)) {
                 // a large input is decoded where it lies; what a round does not use stays with the caller
