@@ -98,6 +98,7 @@ struct GzFile {
      * file position and the index fields belong to that thread: the caller's side touches `carry`, `cur`, `behind_job`,
      * x.pos and the seek request only, and everything else after wait_idle(). */
     unsigned char *carry[2]; size_t carry_n[2], carry_cap; int cur;
+    std::vector<unsigned char, NoInitAlloc<unsigned char> > wout;   /* room for what a whole batch compresses to: deflate() downloads straight into it */
     bool behind_job;                      /* a job is out and has not been waited for */
     std::thread worker; bool worker_on;
     std::mutex wmu; std::condition_variable wcv;
@@ -519,6 +520,26 @@ int comp(GzFile *s, int flush)                          /* gz_comp, gzwrite.c:74
     }
     int ret = Z_OK;
     unsigned made;
+    /* a whole batch (from the thread behind the caller): its output goes to a buffer that holds all of it, so that
+     * deflate() downloads into it directly instead of into a vector of its own that is then copied out 32 MiB at a time */
+    const bool whole = s->carry_cap && z.avail_in == s->carry_cap && flush == Z_NO_FLUSH && !s->wout.empty();
+    if (whole) {
+        const size_t have = (size_t)(z.next_out - s->x.next);
+        if (have && write_all(s, s->x.next, have) == -1) return -1;
+        z.next_out = s->wout.data(); z.avail_out = (uInt)s->wout.size(); s->x.next = z.next_out;
+    }
+    struct Back {       /* whatever happens, the stream is back on the file's ordinary buffer when comp() returns */
+        GzFile *s; bool on;
+        ~Back() {
+            if (!on) return;
+            z_stream &z = s->strm;
+            if (z.next_out >= s->wout.data() && z.next_out <= s->wout.data() + s->wout.size()) {
+                const size_t have = (size_t)(z.next_out - s->x.next);
+                if (have && s->err == Z_OK) (void)write_all(s, s->x.next, have);
+                z.avail_out = s->size; z.next_out = s->out.data(); s->x.next = z.next_out;
+            }
+        }
+    } back = {s, whole};
     do {
         /* the buffer goes out when it is full, and on a flush (for Z_FINISH: once the stream has ended) */
         if (z.avail_out == 0 || (flush != Z_NO_FLUSH && (flush != Z_FINISH || ret == Z_STREAM_END))) {
@@ -671,6 +692,10 @@ int submit(GzFile *s)
             s->strm.next_in = s->carry[k]; s->strm.avail_in = (uInt)n;
             return comp(s, Z_NO_FLUSH);
         }
+    }
+    if (s->wout.empty() && n == s->carry_cap) {
+        try { s->wout.resize((size_t)deflateBound(&s->strm, (uLong)s->carry_cap) + 4096); }
+        catch (...) { /* then through the ordinary buffer */ }
     }
     { std::lock_guard<std::mutex> g(s->wmu); s->job_p = s->carry[k]; s->job_n = n; s->job_ready = true; s->job_done = false; s->job_out = true; }
     s->behind_job = true;
