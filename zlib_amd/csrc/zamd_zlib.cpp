@@ -919,7 +919,9 @@ static int deflate_body(z_streamp strm, int flush) {
             uint64_t take = s->batch_bytes - s->in.size();
             if (take > strm->avail_in) take = strm->avail_in;
             // a caller that writes by the megabyte fills the batch: room for all of it at once, not by doubling and copying
-            if (s->in.capacity() < s->batch_bytes && s->in.size() + take > (16u << 20)) s->in.reserve(s->batch_bytes);
+            if (s->in.capacity() < s->batch_bytes && s->in.size() + take > (16u << 20)) {
+                try { s->in.reserve(s->batch_bytes); } catch (...) { /* an allocator that has no such piece: grow as needed */ }
+            }
             s->in.insert(s->in.end(), strm->next_in, strm->next_in + take);
             strm->next_in += take; strm->avail_in -= (uInt)take; strm->total_in += take;
             if (s->in.size() < s->batch_bytes || (flushing && strm->avail_in == 0)) break;     // (a full batch that is the flush's own: finish_batch)
