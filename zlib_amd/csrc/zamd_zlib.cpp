@@ -1825,6 +1825,10 @@ static int inflate_body(z_streamp strm, int flush) {
             // hundred); the caller's next call, with room, takes them along.  (Without the index the rest may be an
             // empty last block and the trailer, which must not wait for room: inflate.c:1165-1210 needs none either.)
             if (strm->avail_out == 0 && s->bit_off == 0 && s->hint_pos + 1 < s->hints.size() && s->hints[s->hint_pos + 1] != 0) break;
+            // The same without an index when this call has filled the room it was given and a megabyte or more of the
+            // caller's input is left (the end of a stream is a few bytes): that input stays with the caller, whose next
+            // call brings room.  (A call that comes without room is served as before.)
+            if (strm->avail_out == 0 && out0 != 0 && s->in.empty() && strm->avail_in >= (1u << 20)) break;
             bool tried_all = false;
             if ((s->in.empty() || (s->in.size() < (4u << 20) && strm->avail_in >= (8u << 20) && !s->tail_partial)) && strm->avail_in >= (1u << 20)) {
                 // a large input is decoded where it lies; what a round does not use stays with the caller
