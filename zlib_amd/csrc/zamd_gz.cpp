@@ -1434,8 +1434,8 @@ static int gzflush_body(gzFile file, int flush)                                 
     GzFile *s = gz(file);
     if (s == NULL) return -1;
     if (s->mode != GZ_WRITE) return Z_STREAM_ERROR;
-    (void)settle(s);
-    if (s->err != Z_OK) return Z_STREAM_ERROR;
+    if (idle(s) && s->err != Z_OK) return Z_STREAM_ERROR;
+    if (settle(s) == -1) return s->err;                 /* the failure belongs to data that this call was to flush */
     if (flush < 0 || flush > Z_FINISH) return Z_STREAM_ERROR;
     if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return -1; }
     comp(s, flush);
@@ -1452,8 +1452,8 @@ static int gzsetparams_body(gzFile file, int level, int strategy)               
     GzFile *s = gz(file);
     if (s == NULL) return Z_STREAM_ERROR;
     if (s->mode != GZ_WRITE) return Z_STREAM_ERROR;
-    (void)settle(s);
-    if (s->err != Z_OK) return Z_STREAM_ERROR;
+    if (idle(s) && s->err != Z_OK) return Z_STREAM_ERROR;
+    if (settle(s) == -1) return s->err;
     if (level == s->level && strategy == s->strategy) return Z_OK;
     if (s->seek) { s->seek = 0; if (zeros(s, s->skip) == -1) return -1; }
     if (s->size) {
