@@ -379,11 +379,11 @@ template <bool WRITE>
 #define ZI_WAVES_PER_SIMD 5
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ZI_WAVES_PER_SIMD, ZI_WAVES_PER_SIMD))) void k_inf_decode(const uint8_t *comp, uint64_t comp_bytes, ZiSeg *segs, uint32_t nseg, uint16_t *out16,
-                                                                                                                                 uint64_t *bmarks, uint32_t mark_step, uint32_t pair_mode)
+                                                                                                                                 uint64_t *bmarks, uint32_t mark_step, uint32_t pair_mode, const uint32_t *order)
 {
     __shared__ ZiLds L;
     const uint32_t lane = threadIdx.x;
-    const uint32_t si = blockIdx.x;
+    const uint32_t si = order ? order[blockIdx.x] : blockIdx.x;     /* (k_inf_order: the long segments start first) */
     if (si >= nseg) return;
     ZiSeg S = segs[si];
     const bool marking = !WRITE && bmarks != nullptr;        /* only a counting pass reports block marks */
@@ -732,6 +732,35 @@ __global__ void k_inf_setup(const uint64_t *chunk_off, uint64_t nchunks, uint32_
 }
 
 /* result[0] = index of the first segment whose status is not a success, or ~0 */
+/* A launch of more segments than the GPU holds wavefronts ends with the segments that were started last: the order of
+ * the workgroups is the order of the segments by their input length, longest first (in 1024 classes of length; the
+ * order inside a class is whatever the atomics make it, which changes nothing in what is written where). */
+__global__ __launch_bounds__(1024) void k_inf_order(const ZiSeg *segs, uint32_t nseg, uint32_t *order)
+{
+    __shared__ uint32_t cnt[1024];
+    __shared__ unsigned long long longest;
+    const uint32_t t = threadIdx.x;
+    cnt[t] = 0;
+    if (t == 0) longest = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < nseg; i += 1024u) atomicMax(&longest, (unsigned long long)(segs[i].in_end_bit - segs[i].in_bit));
+    __syncthreads();
+    const uint64_t m = longest;
+    const int top = m ? 64 - __clzll((long long)m) : 0;
+    const uint32_t shift = top > 10 ? (uint32_t)(top - 10) : 0u;
+    for (uint32_t i = t; i < nseg; i += 1024u) {
+        const uint64_t c = (segs[i].in_end_bit - segs[i].in_bit) >> shift;
+        atomicAdd(&cnt[1023u - (uint32_t)(c < 1023u ? c : 1023u)], 1u);
+    }
+    __syncthreads();
+    if (t == 0) { uint32_t run = 0; for (uint32_t b = 0; b < 1024u; b++) { const uint32_t c = cnt[b]; cnt[b] = run; run += c; } }
+    __syncthreads();
+    for (uint32_t i = t; i < nseg; i += 1024u) {
+        const uint64_t c = (segs[i].in_end_bit - segs[i].in_bit) >> shift;
+        order[atomicAdd(&cnt[1023u - (uint32_t)(c < 1023u ? c : 1023u)], 1u)] = i;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_inf_status(const ZiSeg *segs, uint64_t nseg, unsigned long long *result)
 {
     unsigned long long best = ~0ull;
@@ -994,6 +1023,7 @@ struct ZiState {
     uint32_t last_status = 0; int64_t last_seg = -1;
     uint64_t *d_scan = nullptr; uint32_t scan_cap = 0;          /* zamd_find_sync_dev's result list */
     uint32_t *d_open = nullptr;                                 /* 64 words: which jump rounds left references behind */
+    uint32_t *d_order = nullptr;                                /* seg_cap words: k_inf_order's list */
     uint64_t *d_bmarks = nullptr; uint64_t bmarks_cap = 0;      /* block marks of a counting pass, a row per segment */
     unsigned long long *h_bmarks = nullptr; uint32_t bmark_step = 0;     /* where the next counting pass is to leave them (zamd_inflate_block_marks) */
     /* a sharded inflate between its begin and finish calls */
@@ -1004,7 +1034,7 @@ static void zi_free(zamd_engine *e)
 {
     ZiState *z = e->inf;
     if (!z) return;
-    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res); hipFree(z->d_flist); hipFree(z->d_scan); hipFree(z->d_bmarks); hipFree(z->d_open);
+    hipFree(z->d_segs); hipFree(z->d_stage); hipFree(z->d_marks); hipFree(z->d_mlist); hipFree(z->d_res); hipFree(z->d_flist); hipFree(z->d_scan); hipFree(z->d_bmarks); hipFree(z->d_open); hipFree(z->d_order);
     delete z; e->inf = nullptr;
 }
 
@@ -1019,10 +1049,11 @@ static int zi_ensure(zamd_engine *e, uint64_t nseg, uint64_t stage_elems, bool r
     if (!z->d_res) HIPCHK(hipMalloc((void **)&z->d_res, 16));
     if (!z->d_open) HIPCHK(hipMalloc((void **)&z->d_open, 64 * 4));
     if (z->seg_cap < nseg) {
-        hipFree(z->d_segs); hipFree(z->d_marks); z->d_segs = nullptr; z->d_marks = nullptr; z->seg_cap = 0;
+        hipFree(z->d_segs); hipFree(z->d_marks); hipFree(z->d_order); z->d_segs = nullptr; z->d_marks = nullptr; z->d_order = nullptr; z->seg_cap = 0;
         uint64_t want = nseg + nseg / 4 + 16;
         if (hipMalloc((void **)&z->d_segs, want * sizeof(ZiSeg)) != hipSuccess) return ZAMD_MEM_ERROR;
         if (hipMalloc((void **)&z->d_marks, want * 4) != hipSuccess) return ZAMD_MEM_ERROR;
+        if (hipMalloc((void **)&z->d_order, want * 4) != hipSuccess) return ZAMD_MEM_ERROR;
         z->seg_cap = want;
     }
     if (resolve && z->mlist_cap < nseg) {     /* marker lists: 32 Ki entries per segment */
@@ -1052,11 +1083,18 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
     HIPCHK(hipMemsetAsync(z->d_res, 0xff, 8, s));
     /* literal pairs in the speculative decode: 0 never, 1 always, 2 where a segment's tokens are mostly literals (tests and measurements set it) */
     static const uint32_t pair_mode = getenv("ZAMD_INF_PAIRS") ? (uint32_t)atoi(getenv("ZAMD_INF_PAIRS")) : 2u;
+    /* more segments than wavefront slots, their input lengths known: the long ones first (ZAMD_INF_ORDER=0: as they come) */
+    static const bool order_on = !(getenv("ZAMD_INF_ORDER") && atoi(getenv("ZAMD_INF_ORDER")) == 0);
+    const uint32_t *order = nullptr;
+    if (d_out && order_on && nseg > ZI_SPLIT_CHUNKS && nseg < (1ull << 31)) {
+        hipLaunchKernelGGL(k_inf_order, dim3(1), dim3(1024), 0, s, z->d_segs, (uint32_t)nseg, z->d_order);
+        order = z->d_order;
+    }
     tm_begin(e, s, 7, &slot);
     if (d_out) hipLaunchKernelGGL((k_inf_decode<true>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, z->d_stage,
-                                  (uint64_t *)nullptr, 0u, pair_mode);
+                                  (uint64_t *)nullptr, 0u, pair_mode, order);
     else hipLaunchKernelGGL((k_inf_decode<false>), dim3((uint32_t)nseg), dim3(64), 0, s, (const uint8_t *)d_comp, comp_bytes, z->d_segs, (uint32_t)nseg, (uint16_t *)nullptr,
-                            bmarks, mark_step, pair_mode);
+                            bmarks, mark_step, pair_mode, (const uint32_t *)nullptr);
     tm_end(e, s, slot);
     hipLaunchKernelGGL(k_inf_status, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, z->d_res);
     unsigned long long bad = ~0ull;
