@@ -864,6 +864,12 @@ __global__ __launch_bounds__(1024) void k_inf_ref_init(const ZiSeg *segs, const 
 /* open[round] is set by a round that leaves a reference behind; a round whose predecessor left none has nothing to do
  * (the rounds are launched for the longest chain the segment count allows; the mixed corpus needs 11 of the 14 at 8 192
  * segments: 11.0 -> 10.0 ms). */
+/* A round follows a reference ZI_JUMP_HOPS steps, not one: every step reads a slot that holds its byte or a pointer
+ * further along the same chain (whether or not another thread has advanced it meanwhile), so a chain shrinks to an
+ * eighth per round at least and 8 192 segments need five rounds, not fourteen.  A round costs a pass over all slots
+ * whatever it finds (0.23 ms per GiB of slots); the extra steps are taken by the slots that still hold references only. */
+#define ZI_JUMP_HOPS 7u
+#define ZI_JUMP_SHIFT 3u            /* log2(ZI_JUMP_HOPS + 1) */
 __global__ __launch_bounds__(256) void k_inf_ref_jump(uint32_t *ref, uint64_t n, uint32_t *open, uint32_t round)
 {
     if (round && !open[round - 1u]) return;
@@ -871,7 +877,8 @@ __global__ __launch_bounds__(256) void k_inf_ref_jump(uint32_t *ref, uint64_t n,
     if (i >= n) return;
     const uint32_t r = ref[i];
     uint32_t nr = r;
-    if (!(r >> 30)) { nr = __hip_atomic_load(ref + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ref[i] = nr; }
+    for (uint32_t h = 0; h < ZI_JUMP_HOPS && !(nr >> 30); h++) nr = __hip_atomic_load(ref + nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (nr != r) ref[i] = nr;
     if (__ballot(!(nr >> 30)) && (threadIdx.x & 63u) == 0) open[round] = 1u;
 }
 /* The same for chunks that were cut into `use` parts, in three steps that touch most slots twice instead of once per
@@ -922,8 +929,10 @@ __global__ __launch_bounds__(1024) void k_inf_ref_jump_last(uint32_t *ref, const
     uint32_t nr = ZI_REF_BYTE;
     if (threadIdx.x >= (g.y & 0xffffu) && threadIdx.x < (g.y >> 16)) {
         const uint32_t i = g.x + threadIdx.x;
-        nr = ref[i];
-        if (!(nr >> 30)) { nr = __hip_atomic_load(ref + nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ref[i] = nr; }
+        const uint32_t r = ref[i];
+        nr = r;
+        for (uint32_t h = 0; h < ZI_JUMP_HOPS && !(nr >> 30); h++) nr = __hip_atomic_load(ref + nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nr != r) ref[i] = nr;
     }
     if (__ballot(!(nr >> 30)) && (threadIdx.x & 63u) == 0) open[round] = 1u;
 }
@@ -967,13 +976,15 @@ __global__ __launch_bounds__(1024) void k_inf_tail_window(const ZiSeg *segs, uin
     win[j] = b;
 }
 
-/* Everything in front of the tails: 8 elements per thread. */
+/* Everything in front of the tails: 16 elements per thread (two 16-byte loads, one 16-byte store; elements that are all
+ * plain bytes, which is nearly all of them behind a segment's first 32 KiB, are packed four to an instruction). */
 /* chunk_size != 0: segment tables of `parts` entries per chunk, the parts of a chunk in stream order with the unused
  * entries (empty, placed at the chunk's end) behind them */
+#define ZI_FINAL_PER_THREAD 16u
 __global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t nseg, uint32_t chunk_size, uint32_t parts, const uint16_t *out16,
                                                    uint8_t *out8, const uint8_t *head, uint64_t total)
 {
-    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * ZI_FINAL_PER_THREAD;
     if (p0 >= total) return;
     uint64_t si;
     if (chunk_size) {
@@ -987,20 +998,26 @@ __global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t n
     ZiSeg S = segs[si];
     uint64_t seg_end = S.out_off + S.out_len;
     uint64_t tail0 = seg_end - (S.out_len < 32768 ? S.out_len : 32768);
-    if (p0 + 8 <= tail0) {
-        const uint4 q = *(const uint4 *)(out16 + p0);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-        uint32_t b[2] = {0, 0};
+    if (p0 + ZI_FINAL_PER_THREAD <= tail0) {
+        const uint4 qa = *(const uint4 *)(out16 + p0), qb = *(const uint4 *)(out16 + p0 + 8);
+        const uint32_t w[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        uint32_t b[4];
+        if (!((qa.x | qa.y | qa.z | qa.w | qb.x | qb.y | qb.z | qb.w) & 0xff00ff00u)) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint32_t v = (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-            if (v >= ZI_MARK) v = zi_window_byte(S, v, out8, head);
-            b[i >> 2] |= v << ((i & 3) * 8);
+            for (int i = 0; i < 4; i++) b[i] = __builtin_amdgcn_perm(w[2 * i + 1], w[2 * i], 0x06040200u);     /* the low bytes of four elements */
+        } else {
+            b[0] = b[1] = b[2] = b[3] = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                uint32_t v = (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
+                if (v >= ZI_MARK) v = zi_window_byte(S, v, out8, head);
+                b[i >> 2] |= v << ((i & 3) * 8);
+            }
         }
-        *(uint2 *)(out8 + p0) = make_uint2(b[0], b[1]);
+        *(uint4 *)(out8 + p0) = make_uint4(b[0], b[1], b[2], b[3]);
         return;
     }
-    for (int i = 0; i < 8; i++) {
+    for (uint32_t i = 0; i < ZI_FINAL_PER_THREAD; i++) {
         const uint64_t p = p0 + i;
         if (p >= total) break;
         while (p >= seg_end && si + 1 < nseg) {
@@ -1132,14 +1149,14 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
                 hipLaunchKernelGGL(k_inf_ref_last_list, dim3((uint32_t)((ngroups + 255) / 256)), dim3(256), 0, s, z->d_segs, ngroups, parts, chunk_size, out_bytes,
                                    z->d_flist, cap, d_count);
                 uint32_t rounds = 1;
-                while ((1ull << rounds) < nchunks) rounds++;
+                while ((1ull << (ZI_JUMP_SHIFT * rounds)) < nchunks) rounds++;
                 HIPCHK(hipMemsetAsync(z->d_open, 0, 64 * 4, s));
                 for (uint32_t r = 0; r <= rounds; r++)
                     hipLaunchKernelGGL(k_inf_ref_jump_last, dim3(cap), dim3(1024), 0, s, z->d_mlist, z->d_flist, d_count, z->d_open, r);
                 hipLaunchKernelGGL(k_inf_ref_rest, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, parts, chunk_size, out_bytes);
             } else {
                 uint32_t rounds = 1;
-                while ((1ull << rounds) < nseg) rounds++;
+                while ((1ull << (ZI_JUMP_SHIFT * rounds)) < nseg) rounds++;
                 HIPCHK(hipMemsetAsync(z->d_open, 0, 64 * 4, s));
                 for (uint32_t r = 0; r <= rounds; r++)
                     hipLaunchKernelGGL(k_inf_ref_jump, dim3((uint32_t)((nref + 255) / 256)), dim3(256), 0, s, z->d_mlist, nref, z->d_open, r);
@@ -1158,7 +1175,7 @@ static int zi_run(zamd_engine *e, const void *d_comp, uint64_t comp_bytes, uint6
             hipLaunchKernelGGL(k_inf_tail_pre, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_stage, (uint8_t *)d_out, z->d_marks, z->d_mlist);
             hipLaunchKernelGGL(k_inf_tail_serial, dim3(1), dim3(1024), 0, s, z->d_segs, nseg, (uint8_t *)d_out, z->d_marks, z->d_mlist, (const uint8_t *)d_head);
         }
-        uint64_t groups = (out_bytes + 2047) / 2048;
+        uint64_t groups = (out_bytes + 256u * ZI_FINAL_PER_THREAD - 1) / (256u * ZI_FINAL_PER_THREAD);
         hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, chunk_size, parts, z->d_stage, (uint8_t *)d_out, (const uint8_t *)d_head, out_bytes);
         tm_end(e, s, slot);
         HIPCHK(hipGetLastError());
@@ -1277,7 +1294,7 @@ static int zi_finish(zamd_engine *e, const void *d_head)
     int slot;
     tm_begin(e, s, 8, &slot);
     hipLaunchKernelGGL(k_inf_ref_write, dim3((uint32_t)nseg * 32u), dim3(1024), 0, s, z->d_segs, z->d_mlist, (uint8_t *)z->pend_out, (const uint8_t *)d_head);
-    const uint64_t groups = (z->pend_out_bytes + 2047) / 2048;
+    const uint64_t groups = (z->pend_out_bytes + 256u * ZI_FINAL_PER_THREAD - 1) / (256u * ZI_FINAL_PER_THREAD);
     hipLaunchKernelGGL(k_inf_final, dim3((uint32_t)groups), dim3(256), 0, s, z->d_segs, nseg, z->pend_chunk, 1u, z->d_stage, (uint8_t *)z->pend_out, (const uint8_t *)d_head, z->pend_out_bytes);
     tm_end(e, s, slot);
     HIPCHK(hipGetLastError());
