@@ -779,6 +779,15 @@ __device__ __forceinline__ uint8_t zi_window_byte(const ZiSeg &S, uint32_t marke
     return head[32768 + q];
 }
 
+/* The same for k_inf_final: the byte lies in a tail (or in the window in front of everything), which an earlier kernel has
+ * written, so an ordinary load serves — sixteen of them in a row from one or two cache lines, where sixteen atomic loads
+ * each went to the L2 by themselves (text, whose segments begin with 32 KiB full of references: 16.3 ms per 8 GiB). */
+__device__ __forceinline__ uint8_t zi_window_byte_written(const ZiSeg &S, uint32_t marker, const uint8_t *out8, const uint8_t *head)
+{
+    const int64_t q = (int64_t)S.out_off - 32768 + (int64_t)zi_mark_index(marker);
+    return q >= 0 ? out8[q] : head[32768 + q];
+}
+
 /* Last 32 KiB of every segment: plain bytes are written out, markers are
  * collected per segment as (offset in the tail) | (window index << 16). */
 __global__ __launch_bounds__(1024) void k_inf_tail_pre(const ZiSeg *segs, const uint16_t *out16, uint8_t *out8, uint32_t *marks, uint32_t *mlist)
@@ -1010,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t n
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 uint32_t v = (w[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-                if (v >= ZI_MARK) v = zi_window_byte(S, v, out8, head);
+                if (v >= ZI_MARK) v = zi_window_byte_written(S, v, out8, head);
                 b[i >> 2] |= v << ((i & 3) * 8);
             }
         }
@@ -1025,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_inf_final(const ZiSeg *segs, uint64_t n
         }
         if (p < S.out_off || p >= tail0) continue;      /* tails are already written */
         uint32_t v = out16[p];
-        if (v >= ZI_MARK) v = zi_window_byte(S, v, out8, head);
+        if (v >= ZI_MARK) v = zi_window_byte_written(S, v, out8, head);
         out8[p] = (uint8_t)v;
     }
 }
