@@ -34,7 +34,12 @@ def work(k, reps=2):
 
 
 for k in range(nt):
-    work(k, 1)                  # warm: engines, buffers
+    work(k, 1)                  # warm: the first lane's engine, the buffers
+ths = [threading.Thread(target=work, args=(k, 1)) for k in range(nt)]
+for t in ths:
+    t.start()                   # warm: the engines of the other lanes, which only threads at once bring up
+for t in ths:
+    t.join()
 t0 = time.time()
 for k in range(nt):
     work(k)
