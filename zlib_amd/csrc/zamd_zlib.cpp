@@ -1416,7 +1416,10 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         // at or behind the next guess; a guess that is no block start just ends the chain there for this round.
         std::vector<uint64_t> bc;
         {
-            static const uint64_t STEP = (getenv("ZAMD_Z_BLOCKSCAN_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_KIB"), nullptr, 10) : 32) * 8192ull;
+            // (a round of a few megabytes is as slow as its longest segment, 4 ms of one wavefront per deflate block of
+            // some 35 KiB: guesses 16 KiB apart find every block, 32 KiB apart leave segments of two)
+            static const uint64_t step_env = getenv("ZAMD_Z_BLOCKSCAN_KIB") ? strtoull(getenv("ZAMD_Z_BLOCKSCAN_KIB"), nullptr, 10) * 8192ull : ~0ull;
+            const uint64_t STEP = step_env != ~0ull ? step_env : (in_n <= (32ull << 20) ? 16 : 32) * 8192ull;
             if (STEP && end_bits > s->bit_off + 2 * STEP) {
                 // only where sync markers are further apart than GAP.  A wavefront inflates about 20 MB a second: a round of
                 // few segments takes as long as its longest one, so a small round is cut finer than its sync markers cut it
@@ -1461,7 +1464,9 @@ int decode_some(z_streamp strm, IState *s, const uint8_t *ext = nullptr, size_t 
         // the counting pass notes block boundaries inside its segments (one about every MARK_STEP bytes of output): the pass
         // that writes the output cuts the segments there, a wavefront to a part (a 1 MiB chunk is some 50 ms of one
         // wavefront's time)
-        static const uint32_t MARK_STEP = (uint32_t)env_u64("ZAMD_Z_INF_MARK_KIB", 128) << 10;
+        // (in a small round every block boundary is a mark: its parts are single blocks, and the round is as slow as its longest part)
+        static const uint32_t mark_env = getenv("ZAMD_Z_INF_MARK_KIB") ? (uint32_t)env_u64("ZAMD_Z_INF_MARK_KIB", 128) << 10 : ~0u;
+        const uint32_t MARK_STEP = mark_env != ~0u ? mark_env : in_n <= (32ull << 20) ? (32u << 10) : (128u << 10);
         if (MARK_STEP) {
             marks.assign(segs.size() * ZAMD_INF_MARKS, 0ull);
             for (const zamd_inflate_seg &g : segs) mark_bits.push_back(g.in_bit);
