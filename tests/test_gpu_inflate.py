@@ -127,6 +127,26 @@ def test_long_range_window_propagation(engine):
     assert engine.inflate_chunks(stream, offs, len(data), chunk_size=131072, splits=splits, parts=16) == data
 
 
+def test_more_segments_than_wavefront_slots_and_chains_as_long_as_the_data(engine):
+    """More segments than the GPU holds wavefronts of the decode kernel (5 120): the launch takes them longest first
+    (k_inf_order), and references that run back through every segment — a run of one byte from the first chunk to the
+    last — are followed by the jump rounds, eight steps a round.  Zeros, a period, and text between runs."""
+    chunk, n_chunks = 32768, 6000
+    n = chunk * n_chunks
+    text = O.corpus(3 << 20, 4, 9)
+    cases = [
+        b"\0" * n,
+        (b"abcdefg" * (n // 7 + 1))[:n],
+        (b"\x55" * (40 << 20) + text + b"\x55" * n)[:n],
+        (text * (n // len(text) + 1))[:n],
+    ]
+    for data in cases:
+        for level in (1, 6):
+            stream, offs = engine.deflate_chunks(data, level=level, chunk_size=chunk)
+            assert len(offs) - 1 == n_chunks
+            assert engine.inflate_chunks(stream, offs, n, chunk_size=chunk) == data
+
+
 @pytest.mark.parametrize("level,wbits_data", [(1, 0), (6, 1), (9, 4)])
 def test_foreign_single_stream(engine, level, wbits_data):
     # a stream that was not cut into chunks (system zlib as the producer): one segment, one wavefront
