@@ -21,6 +21,7 @@
 #include <errno.h>
 #include <fcntl.h>
 #include <limits.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -29,6 +30,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -629,8 +631,11 @@ void worker_loop(GzFile *s)
  * job that is still running: the files that have a thread are listed, and exit() waits for their jobs. */
 std::mutex g_files_mu;
 std::vector<GzFile *> g_files;
+std::atomic<bool> g_forked{false};      /* this process is a fork()ed child: the threads and their jobs stayed with the parent */
+void in_forked_child() { g_forked.store(true); }
 void wait_at_exit()
 {
+    if (g_forked.load()) return;
     const bool trace = getenv("ZAMD_Z_TRACE") != nullptr;
     std::lock_guard<std::mutex> l(g_files_mu);
     for (GzFile *s : g_files) {
@@ -646,7 +651,7 @@ void start_worker(GzFile *s)                            /* throws what std::thre
      * the hook below (handlers run in the reverse order), not under a job that is still using it */
     if (zamd_z_engine_ready() != Z_OK) throw std::bad_alloc();
     std::lock_guard<std::mutex> l(g_files_mu);
-    static const bool hooked = atexit(wait_at_exit) == 0;
+    static const bool hooked = atexit(wait_at_exit) == 0 && pthread_atfork(NULL, NULL, in_forked_child) == 0;
     (void)hooked;
     g_files.push_back(s);
     try { s->worker = std::thread(worker_loop, s); }
